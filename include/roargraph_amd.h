@@ -1,0 +1,132 @@
+/*
+ * roargraph_amd.h -- C ABI of the MI355X-native RoarGraph search engine.
+ *
+ * This is the drop-in boundary for ONE path of matchyc/mysteryann: the batched best-first beam
+ * search over the projected (RoarGraph) graph, i.e. IndexBipartite::SearchRoarGraph and what it
+ * calls.  Everything below the line is hand-written HIP for gfx950; there is no CPU fallback --
+ * every compute entry point fails with ROAR_ERR_DEVICE when no HIP device is present.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; no C++ or torch types.  All functions return ROAR_OK (0)
+ * or a negative code and never throw; roar_last_error() returns the thread-local message, which
+ * for the cases the reference throws on carries the reference's own text.
+ */
+#ifndef ROARGRAPH_AMD_H
+#define ROARGRAPH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct roar_index roar_index;
+
+/* include/efanna2e/distance.h:15 (FAST_L2 = 2 and PQ = 3 are never instantiated on the path) */
+enum { ROAR_METRIC_L2 = 0, ROAR_METRIC_IP = 1, ROAR_METRIC_COSINE = 4 };
+
+enum {
+    ROAR_OK = 0,
+    ROAR_ERR_ARG = -1,    /* bad argument / state (std::invalid_argument in the reference) */
+    ROAR_ERR_IO = -2,     /* cannot open file (reference: exit(-1) util.h:109-112 / "cannot open file") */
+    ROAR_ERR_FORMAT = -3, /* "Data file size wrong!" (util.h:124,205-208) */
+    ROAR_ERR_DEVICE = -4, /* no HIP device, HIP runtime error, out of device memory */
+    ROAR_ERR_SHORT = -5   /* "not enough results: x, expected: k" (src/index_bipartite.cpp:2408-2412) */
+};
+
+/* visited-set policy, option "visited_mode" (replaces VisitedList / VisitedListPool,
+ * include/visited_list_pool.h:8-74):
+ *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
+ *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
+ *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1 };
+
+/* ---- lifecycle ------------------------------------------------------------------------------
+ * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
+ * Index::Index metric -> distance choice                          src/index.cpp:8-25.
+ * `dim` is the UNPADDED vector dimension; rows are padded to a multiple of 8 floats on load
+ * (util.h:37-75).  `device` is the HIP device ordinal. */
+int roar_create(roar_index **out, uint32_t dim, int metric, int device);
+void roar_destroy(roar_index *idx);
+const char *roar_last_error(void);
+
+/* ---- base vectors ---------------------------------------------------------------------------
+ * IndexBipartite::LoadVectorData / LoadSearchNeededData  src/index_bipartite.cpp:2661-2692,
+ * load_meta / load_data / data_align / normalize         include/efanna2e/util.h:37-75,106-127,179-225.
+ * COSINE indexes L2-normalise every row before upload (src/index_bipartite.cpp:2676-2681). */
+int roar_load_base_fbin(roar_index *idx, const char *path);
+/* Same, from caller memory: n rows of `dim` valid floats at `row_stride_floats` stride (host). */
+int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_stride_floats);
+/* Adopt rows already resident in HBM (no copy, caller keeps ownership and must outlive the index).
+ * row_stride_floats must be a multiple of 4 and >= the padded dim with zero padding in place. */
+int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats);
+
+/* ---- graph ----------------------------------------------------------------------------------
+ * IndexBipartite::LoadProjectionGraph  src/index_bipartite.cpp:2097-2117
+ * IndexBipartite::SaveProjectionGraph  src/index_bipartite.cpp:2606-2619
+ * File: u32 ep; u32 npts; npts x {u32 deg; u32 nbr[deg]}.  Neighbour order is preserved (it is
+ * the scan order of the search).  The CSR form is projection_graph_ (index_bipartite.h:150). */
+int roar_load_graph_file(roar_index *idx, const char *path);
+int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t *offsets, const uint32_t *nbrs);
+int roar_save_graph_file(roar_index *idx, const char *path);
+/* Copy the graph back out (host buffers; pass NULL nbrs to query sizes only). */
+int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *nedges, uint64_t *offsets,
+                       uint32_t *nbrs);
+
+/* ---- search ---------------------------------------------------------------------------------
+ * IndexBipartite::SearchRoarGraph  src/index_bipartite.cpp:2311-2420, batched over nq queries
+ * (the reference's `#pragma omp parallel for` over queries, tests/test_search_roargraph.cpp:203-209,
+ * becomes one launch).  Per query: ids[k], dists[k] (IP: negated dot, L2: squared), cmps, hops
+ * (the pair the reference returns, :2419) and optionally scanned = sum of expanded degrees.
+ * `queries`: nq rows at `qstride_floats` stride holding at least `dim` floats each; for COSINE the
+ * caller normalises queries first, as the harness does (tests/test_search_roargraph.cpp:167-172).
+ * Host-buffer form: H2D of queries, launch, D2H of results.  Any of cmps/hops/scanned may be NULL.
+ * Returns ROAR_ERR_SHORT if some query ended with fewer than k results (their tail ids are
+ * 0xFFFFFFFF); the other queries' results are still valid. */
+int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                      uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
+                      uint32_t *scanned);
+/* Device-buffer form: every pointer is HBM-resident, launch is asynchronous on `hip_stream`
+ * (a hipStream_t, NULL = default stream); no implicit synchronisation.  Short results are reported
+ * through *short_count_dev (u32, may be NULL). */
+int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats,
+                             uint32_t k, uint32_t L_pq, uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev,
+                             uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
+                             void *hip_stream);
+
+/* ---- distance kernels alone -----------------------------------------------------------------
+ * DistanceL2::compare / DistanceInnerProduct::compare  include/efanna2e/distance.h:39-89,179-223.
+ * out[q * m + j] = distance(base[ids[q * m + j]], queries[q]) with the index's metric, computed
+ * by the same device routine the search uses (bit-identical to the reference's AVX-512 + FMA
+ * summation order).  Host buffers. */
+int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats,
+                   const uint32_t *ids, uint32_t m, float *out);
+
+/* ---- top-k merge for the index-sharded configuration ------------------------------------------
+ * Not in the reference (new capability): merge `nshards` per-shard sorted top-k lists
+ * per query by (distance, id) into a global top-k.  Device buffers laid out [shard][nq][k]. */
+int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
+                           const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream);
+
+/* ---- options / introspection ----------------------------------------------------------------
+ * Parameters::Set / Get  include/efanna2e/parameters.h:15-57 carry L_pq per call in the reference;
+ * here L_pq is an argument and the remaining knobs are integers:
+ *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS (default LDS)
+ *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto)
+ *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq; power of two)
+ *   "max_grid"       cap on the number of resident waves launched (0 = no cap)
+ * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
+ *   "row_stride", "last_grid", "last_lds_bytes", "last_vis_entries", "last_kernel_ns"
+ *   (duration of the most recent search kernel, measured with HIP events on its own stream;
+ *   reading it synchronises on those events). */
+int roar_set_option(roar_index *idx, const char *key, int64_t value);
+int roar_get_info(roar_index *idx, const char *key, int64_t *value);
+
+/* InitVisitedListPool(num_threads)  include/index_bipartite.h:133: sizes the EXACT-mode tag pool
+ * (one u8[n] list per resident wave).  Optional: done lazily by the first EXACT search. */
+int roar_init_visited_pool(roar_index *idx, uint32_t slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROARGRAPH_AMD_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI (include/roargraph_amd.h) -- the only way Python reaches the
+product.  There is no Python / CPU implementation of the search behind it: if the HIP library is
+missing or no GPU is present every compute call raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libroargraph_amd.so")
+
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 4
+VISITED_EXACT, VISITED_LDS = 0, 1
+OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_SHORT = 0, -1, -2, -3, -4, -5
+
+# every symbol include/roargraph_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
+    "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
+    "roar_get_graph_csr", "roar_search_batch", "roar_search_batch_device", "roar_distances",
+    "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
+]
+
+
+class RoarError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_capi.cpp", "roar_device.h")]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _CSRC, "lib"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RoarError(ERR_DEVICE, "libroargraph_amd.so is not built (run __graft_entry__.build()); "
+                                    "there is no fallback implementation")
+    l = C.CDLL(LIB_PATH)
+    vp, u32p, u64p, fp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+    l.roar_last_error.restype = C.c_char_p
+    l.roar_create.argtypes = [C.POINTER(vp), C.c_uint32, C.c_int, C.c_int]
+    l.roar_destroy.argtypes = [vp]
+    l.roar_destroy.restype = None
+    l.roar_load_base_fbin.argtypes = [vp, C.c_char_p]
+    l.roar_set_base.argtypes = [vp, fp, C.c_uint64, C.c_uint32]
+    l.roar_set_base_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+    l.roar_load_graph_file.argtypes = [vp, C.c_char_p]
+    l.roar_set_graph_csr.argtypes = [vp, C.c_uint32, C.c_uint64, u64p, u32p]
+    l.roar_save_graph_file.argtypes = [vp, C.c_char_p]
+    l.roar_get_graph_csr.argtypes = [vp, u32p, u64p, u64p, u64p, u32p]
+    l.roar_search_batch.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, u32p, u32p]
+    l.roar_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
+                                           vp, vp]
+    l.roar_distances.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, C.c_uint32, fp]
+    l.roar_merge_topk_device.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
+    l.roar_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    l.roar_init_visited_pool.argtypes = [vp, C.c_uint32]
+    for s in SYMBOLS:
+        if s not in ("roar_destroy", "roar_last_error"):
+            getattr(l, s).restype = C.c_int
+    _lib = l
+    return l
+
+
+def check(rc):
+    if rc != OK:
+        raise RoarError(rc, lib().roar_last_error().decode("utf-8", "replace"))
+
+
+def f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))

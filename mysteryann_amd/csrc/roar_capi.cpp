@@ -1,0 +1,691 @@
+// roar_capi.cpp -- C ABI (include/roargraph_amd.h) over the HIP kernels: index object, loaders
+// for the reference's on-disk formats, HBM layout, launch configuration.  Host-only code built
+// with hipcc.  There is deliberately no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/roargraph_amd.h"
+#include "roar_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(ROAR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct roar_index {
+    int device = 0;
+    uint32_t dim = 0, dim_pad = 0;
+    int metric = ROAR_METRIC_L2;
+    bool ip = false, need_normalize = false;
+    int n_cus = 0;
+    // base rows in HBM
+    float *base = nullptr;
+    bool base_owned = false;
+    uint64_t n = 0;
+    uint32_t ld = 0;
+    // graph in HBM (fixed-stride rows) + host CSR copy for save / get
+    uint32_t *adj = nullptr;
+    uint32_t adj_stride = 0, ep = 0, max_deg = 0;
+    uint64_t gn = 0, nedges = 0;
+    std::vector<uint64_t> h_off;
+    std::vector<uint32_t> h_nbrs;
+    // options
+    int visited_mode = ROAR_VISITED_LDS;
+    int waves_per_cu = 0;
+    int vis_entries = 0;
+    int max_grid = 0;
+    // workspaces
+    uint32_t *counters = nullptr;  // [0] dequeue counter, [1] short count
+    uint8_t *tags = nullptr;
+    uint32_t *epochs = nullptr;
+    uint32_t slots = 0;
+    uint64_t tag_stride = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // host-API staging
+    float *q_dev = nullptr;
+    uint64_t q_cap = 0;
+    uint32_t *out_dev = nullptr;
+    uint64_t out_cap = 0;
+    // last launch
+    int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
+};
+
+namespace {
+
+int use_device(roar_index *idx) {
+    HIP_TRY(hipSetDevice(idx->device));
+    return ROAR_OK;
+}
+
+void free_graph(roar_index *idx) {
+    if (idx->adj) (void)hipFree(idx->adj);
+    idx->adj = nullptr;
+    idx->h_off.clear();
+    idx->h_nbrs.clear();
+    idx->gn = idx->nedges = 0;
+}
+
+void free_base(roar_index *idx) {
+    if (idx->base && idx->base_owned) (void)hipFree(idx->base);
+    idx->base = nullptr;
+    idx->base_owned = false;
+    idx->n = 0;
+}
+
+void free_tags(roar_index *idx) {
+    if (idx->tags) (void)hipFree(idx->tags);
+    if (idx->epochs) (void)hipFree(idx->epochs);
+    idx->tags = nullptr;
+    idx->epochs = nullptr;
+    idx->slots = 0;
+}
+
+// util.h:214-225
+void normalize_row(float *arr, size_t dim) {
+    float sum = 0.0f;
+    for (size_t i = 0; i < dim; ++i) sum += arr[i] * arr[i];
+    sum = std::sqrt(sum);
+    for (size_t i = 0; i < dim; ++i) arr[i] = arr[i] / sum;
+}
+
+int alloc_base(roar_index *idx, uint64_t n) {
+    free_base(idx);
+    free_tags(idx);
+    idx->ld = idx->dim_pad;
+    HIP_TRY(hipMalloc((void **)&idx->base, (size_t)n * idx->ld * sizeof(float)));
+    idx->base_owned = true;
+    idx->n = n;
+    return ROAR_OK;
+}
+
+// Upload host rows [r0, r0+cnt) already padded to dim_pad.
+int upload_rows(roar_index *idx, const float *padded, uint64_t r0, uint64_t cnt) {
+    HIP_TRY(hipMemcpy(idx->base + r0 * idx->ld, padded, (size_t)cnt * idx->ld * sizeof(float), hipMemcpyHostToDevice));
+    return ROAR_OK;
+}
+
+int ensure_tags(roar_index *idx, uint32_t slots) {
+    if (idx->tags && idx->slots >= slots) return ROAR_OK;
+    free_tags(idx);
+    idx->tag_stride = ((idx->n + 15) / 16) * 16;
+    if (idx->tag_stride == 0) idx->tag_stride = 16;
+    HIP_TRY(hipMalloc((void **)&idx->tags, (size_t)slots * idx->tag_stride));
+    HIP_TRY(hipMemset(idx->tags, 0, (size_t)slots * idx->tag_stride));
+    HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->epochs, 0, (size_t)slots * sizeof(uint32_t)));
+    idx->slots = slots;
+    return ROAR_OK;
+}
+
+struct LaunchPlan {
+    RoarSearchParams p;
+    uint32_t grid;
+};
+
+// LDS carve-up and grid for one search launch.
+int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan) {
+    if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "search before base vectors were loaded");
+    if (!idx->adj) return fail(ROAR_ERR_ARG, "search before the projection graph was loaded");
+    if (idx->gn != idx->n)
+        return fail(ROAR_ERR_ARG, "graph has %llu nodes but base has %llu rows", (unsigned long long)idx->gn,
+                    (unsigned long long)idx->n);
+    if (L == 0 || k == 0) return fail(ROAR_ERR_ARG, "k and L_pq must be positive");
+    if (k > L) return fail(ROAR_ERR_ARG, "L_pq must greater or equal than k");  // tests/test_search_roargraph.cpp:192-195
+    if (idx->n >= (1ull << 31)) return fail(ROAR_ERR_ARG, "more than 2^31 base points are not supported");
+    if (nq >= (1ull << 32)) return fail(ROAR_ERR_ARG, "too many queries in one batch");
+    RoarSearchParams &p = plan->p;
+    memset(&p, 0, sizeof p);
+    p.base = idx->base;
+    p.ld = idx->ld;
+    p.dim = idx->dim_pad;
+    p.adj = idx->adj;
+    p.adj_stride = idx->adj_stride;
+    p.n = (uint32_t)idx->n;
+    p.ep = idx->ep;
+    p.nq = (uint32_t)nq;
+    p.k = k;
+    p.L = L;
+    // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
+    uint32_t sets_log2 = 0;
+    uint32_t entries = 0;
+    if (idx->visited_mode == ROAR_VISITED_LDS) {
+        uint32_t want = idx->vis_entries > 0 ? (uint32_t)idx->vis_entries : 64u * L;
+        if (idx->vis_entries <= 0) want = std::min(std::max(want, 2048u), 16384u);
+        uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
+        uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
+        while ((1u << sets_log2) < sets) sets_log2++;
+        entries = 4u << sets_log2;
+        if ((uint64_t)entries * 2 > 128 * 1024)
+            return fail(ROAR_ERR_ARG, "visited table of %u entries does not fit in LDS", entries);
+    }
+    p.vis_sets_log2 = sets_log2;
+    uint32_t off = 0;
+    p.off_pool = off;
+    off += round_up(8 * (L + 1), 16);
+    p.off_ck = off;
+    off += 8 * 64;
+    p.off_cid = off;
+    off += 4 * 64;
+    p.off_q = off;
+    off += round_up(4 * idx->dim_pad, 16);
+    p.off_vis = off;
+    off += 2 * entries;
+    p.lds_bytes = off;
+    if (p.lds_bytes > 160 * 1024) return fail(ROAR_ERR_ARG, "L_pq = %u needs %u bytes of LDS per query (max 163840)", L, off);
+    int occ = 0;
+    int rc = roar_search_occupancy(idx->ip ? 1 : 0, idx->visited_mode, idx->dim_pad, p.lds_bytes, &occ);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+    if (occ < 1) occ = 1;
+    int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
+    uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
+    if (grid > nq) grid = nq;
+    if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;
+    if (grid == 0) grid = 1;
+    plan->grid = (uint32_t)grid;
+    if (idx->visited_mode == ROAR_VISITED_EXACT) {
+        int e = ensure_tags(idx, std::max<uint32_t>(plan->grid, idx->slots));
+        if (e) return e;
+        p.tags = idx->tags;
+        p.tag_stride = idx->tag_stride;
+        p.epochs = idx->epochs;
+    }
+    p.counter = idx->counters;
+    idx->last_grid = plan->grid;
+    idx->last_lds = p.lds_bytes;
+    idx->last_vis_entries = entries;
+    return ROAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *roar_last_error(void) { return g_err.c_str(); }
+
+int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
+    if (!out) return fail(ROAR_ERR_ARG, "null output pointer");
+    *out = nullptr;
+    if (dim == 0) return fail(ROAR_ERR_ARG, "dimension must be positive");
+    if (metric != ROAR_METRIC_L2 && metric != ROAR_METRIC_IP && metric != ROAR_METRIC_COSINE)
+        return fail(ROAR_ERR_ARG, "unknown metric %d", metric);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(ROAR_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(ROAR_ERR_ARG, "device %d out of range (%d devices)", device, count);
+    roar_index *idx = new roar_index();
+    idx->device = device;
+    idx->dim = dim;
+    idx->dim_pad = round_up(dim, 8);  // DATA_ALIGN_FACTOR, util.h:38-48
+    idx->metric = metric;
+    idx->ip = metric != ROAR_METRIC_L2;          // src/index.cpp:11-24
+    idx->need_normalize = metric == ROAR_METRIC_COSINE;  // src/index_bipartite.cpp:35-37
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    idx->n_cus = prop.multiProcessorCount;
+    HIP_TRY(hipMalloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
+    HIP_TRY(hipEventCreate(&idx->ev0));
+    HIP_TRY(hipEventCreate(&idx->ev1));
+    *out = idx;
+    return ROAR_OK;
+}
+
+void roar_destroy(roar_index *idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    free_graph(idx);
+    free_base(idx);
+    free_tags(idx);
+    if (idx->counters) (void)hipFree(idx->counters);
+    if (idx->q_dev) (void)hipFree(idx->q_dev);
+    if (idx->out_dev) (void)hipFree(idx->out_dev);
+    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    delete idx;
+}
+
+int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_stride_floats) {
+    if (!idx || !rows || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
+    if (row_stride_floats < idx->dim) return fail(ROAR_ERR_ARG, "row stride smaller than the dimension");
+    int e = use_device(idx);
+    if (e) return e;
+    if ((e = alloc_base(idx, n))) return e;
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (idx->ld * sizeof(float)));
+    std::vector<float> buf((size_t)chunk * idx->ld);
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        uint64_t cnt = std::min(chunk, n - r0);
+        for (uint64_t i = 0; i < cnt; ++i) {
+            float *dst = buf.data() + i * idx->ld;
+            memcpy(dst, rows + (r0 + i) * row_stride_floats, idx->dim * sizeof(float));
+            memset(dst + idx->dim, 0, (idx->ld - idx->dim) * sizeof(float));
+            if (idx->need_normalize) normalize_row(dst, idx->dim);
+        }
+        if ((e = upload_rows(idx, buf.data(), r0, cnt))) return e;
+    }
+    return ROAR_OK;
+}
+
+int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats) {
+    if (!idx || !rows_dev || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
+    if (row_stride_floats < idx->dim_pad || (row_stride_floats & 3))
+        return fail(ROAR_ERR_ARG, "device rows need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
+    if (idx->need_normalize) return fail(ROAR_ERR_ARG, "COSINE rows must be normalised by the caller before adoption");
+    int e = use_device(idx);
+    if (e) return e;
+    free_base(idx);
+    free_tags(idx);
+    idx->base = const_cast<float *>(rows_dev);
+    idx->base_owned = false;
+    idx->n = n;
+    idx->ld = row_stride_floats;
+    return ROAR_OK;
+}
+
+int roar_load_base_fbin(roar_index *idx, const char *path) {
+    if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ROAR_ERR_IO, "open file error");  // util.h:109-112
+    uint32_t hdr[2];
+    if (fread(hdr, 4, 2, f) != 2) {
+        fclose(f);
+        return fail(ROAR_ERR_FORMAT, "Data file size wrong!");
+    }
+    fseek(f, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftell(f);
+    const uint32_t n = hdr[0], d = hdr[1];
+    // load_meta: (fsize - 8) / d / 4 must equal n (util.h:118-125)
+    if (d == 0 || (uint32_t)((fsize - 8) / d / 4) != n) {
+        fclose(f);
+        return fail(ROAR_ERR_FORMAT, "Data file size wrong!");
+    }
+    if (d != idx->dim) {
+        fclose(f);
+        return fail(ROAR_ERR_ARG, "base and query dimension mismatch");  // src/index_bipartite.cpp:2667-2669
+    }
+    int e = use_device(idx);
+    if (!e) e = alloc_base(idx, n);
+    if (e) {
+        fclose(f);
+        return e;
+    }
+    fseek(f, 8, SEEK_SET);
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (idx->ld * sizeof(float)));
+    std::vector<float> buf((size_t)chunk * idx->ld);
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        uint64_t cnt = std::min<uint64_t>(chunk, n - r0);
+        for (uint64_t i = 0; i < cnt; ++i) {  // load_data, util.h:196-200
+            float *dst = buf.data() + i * idx->ld;
+            if (fread(dst, 4, d, f) != d) {
+                fclose(f);
+                return fail(ROAR_ERR_FORMAT, "Data file size wrong!");
+            }
+            memset(dst + d, 0, (idx->ld - d) * sizeof(float));
+            if (idx->need_normalize) normalize_row(dst, d);
+        }
+        if ((e = upload_rows(idx, buf.data(), r0, cnt))) {
+            fclose(f);
+            return e;
+        }
+    }
+    fclose(f);
+    return ROAR_OK;
+}
+
+int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t *offsets, const uint32_t *nbrs) {
+    if (!idx || !offsets || (n && !nbrs && offsets[n] != 0)) return fail(ROAR_ERR_ARG, "bad graph arguments");
+    if (n == 0 || n >= (1ull << 31)) return fail(ROAR_ERR_ARG, "graph must have between 1 and 2^31 nodes");
+    if (ep >= n) return fail(ROAR_ERR_FORMAT, "entry point %u outside the graph (%llu nodes)", ep, (unsigned long long)n);
+    int e = use_device(idx);
+    if (e) return e;
+    uint32_t max_deg = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(ROAR_ERR_FORMAT, "CSR offsets are not monotone");
+        uint64_t d = offsets[i + 1] - offsets[i];
+        if (d > 0xFFFFFFu) return fail(ROAR_ERR_FORMAT, "node %llu has an implausible degree", (unsigned long long)i);
+        max_deg = std::max<uint32_t>(max_deg, (uint32_t)d);
+    }
+    const uint64_t ne = offsets[n];
+    for (uint64_t j = 0; j < ne; ++j)
+        if (nbrs[j] >= n) return fail(ROAR_ERR_FORMAT, "neighbour id %u outside the graph", nbrs[j]);
+    free_graph(idx);
+    idx->h_off.assign(offsets, offsets + n + 1);
+    idx->h_nbrs.assign(nbrs, nbrs + ne);
+    idx->ep = ep;
+    idx->gn = n;
+    idx->nedges = ne;
+    idx->max_deg = max_deg;
+    // rows start on 128-byte lines; 64 words of slack so that a 64-lane chunk read never leaves the buffer
+    idx->adj_stride = round_up(max_deg + 1, 32);
+    const size_t words = (size_t)n * idx->adj_stride + 64;
+    HIP_TRY(hipMalloc((void **)&idx->adj, words * sizeof(uint32_t)));
+    // Build rows in chunks.  A neighbour repeated inside one list is kept once (first occurrence):
+    // the reference skips the repeat through its visited test (index_bipartite.cpp:2378), so the
+    // search result and cmps are unchanged, and the device visited filter sees distinct ids per row.
+    std::vector<uint32_t> stamp((size_t)n, 0xFFFFFFFFu);
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (idx->adj_stride * 4));
+    std::vector<uint32_t> buf((size_t)chunk * idx->adj_stride);
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        uint64_t cnt = std::min(chunk, n - r0);
+        std::fill(buf.begin(), buf.begin() + cnt * idx->adj_stride, 0u);
+        for (uint64_t i = 0; i < cnt; ++i) {
+            uint32_t *row = buf.data() + i * idx->adj_stride;
+            uint32_t deg = 0;
+            for (uint64_t j = offsets[r0 + i]; j < offsets[r0 + i + 1]; ++j) {
+                uint32_t nb = nbrs[j];
+                if (stamp[nb] == (uint32_t)(r0 + i)) continue;
+                stamp[nb] = (uint32_t)(r0 + i);
+                row[1 + deg++] = nb;
+            }
+            row[0] = deg;
+        }
+        HIP_TRY(hipMemcpy(idx->adj + r0 * idx->adj_stride, buf.data(), (size_t)cnt * idx->adj_stride * 4,
+                          hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(idx->adj + (size_t)n * idx->adj_stride, 0, 64 * sizeof(uint32_t)));
+    return ROAR_OK;
+}
+
+int roar_load_graph_file(roar_index *idx, const char *path) {
+    if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ROAR_ERR_IO, "cannot open file");
+    fseek(f, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (fsize < 8 || (fsize & 3)) {
+        fclose(f);
+        return fail(ROAR_ERR_FORMAT, "graph file truncated");
+    }
+    std::vector<uint32_t> raw((size_t)(fsize / 4));
+    if (fread(raw.data(), 4, raw.size(), f) != raw.size()) {
+        fclose(f);
+        return fail(ROAR_ERR_FORMAT, "graph file truncated");
+    }
+    fclose(f);
+    const uint32_t ep = raw[0], npts = raw[1];  // src/index_bipartite.cpp:2101-2104
+    std::vector<uint64_t> off((size_t)npts + 1);
+    std::vector<uint32_t> nb;
+    nb.reserve(raw.size());
+    size_t p = 2;
+    for (uint32_t i = 0; i < npts; ++i) {
+        if (p >= raw.size()) return fail(ROAR_ERR_FORMAT, "graph file truncated");
+        uint32_t deg = raw[p++];
+        if (p + deg > raw.size()) return fail(ROAR_ERR_FORMAT, "graph file truncated");
+        off[i] = nb.size();
+        nb.insert(nb.end(), raw.begin() + p, raw.begin() + p + deg);
+        p += deg;
+    }
+    off[npts] = nb.size();
+    static const uint32_t dummy = 0;
+    return roar_set_graph_csr(idx, ep, npts, off.data(), nb.empty() ? &dummy : nb.data());
+}
+
+int roar_save_graph_file(roar_index *idx, const char *path) {
+    if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (idx->gn == 0) return fail(ROAR_ERR_ARG, "no graph loaded");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ROAR_ERR_IO, "cannot open file");  // src/index_bipartite.cpp:2608-2610
+    uint32_t hdr[2] = {idx->ep, (uint32_t)idx->gn};
+    fwrite(hdr, 4, 2, f);
+    for (uint64_t i = 0; i < idx->gn; ++i) {
+        uint32_t deg = (uint32_t)(idx->h_off[i + 1] - idx->h_off[i]);
+        fwrite(&deg, 4, 1, f);
+        fwrite(idx->h_nbrs.data() + idx->h_off[i], 4, deg, f);
+    }
+    fclose(f);
+    return ROAR_OK;
+}
+
+int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *nedges, uint64_t *offsets,
+                       uint32_t *nbrs) {
+    if (!idx) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (ep) *ep = idx->ep;
+    if (n) *n = idx->gn;
+    if (nedges) *nedges = idx->nedges;
+    if (offsets && idx->gn) memcpy(offsets, idx->h_off.data(), (idx->gn + 1) * sizeof(uint64_t));
+    if (nbrs && idx->nedges) memcpy(nbrs, idx->h_nbrs.data(), idx->nedges * sizeof(uint32_t));
+    return ROAR_OK;
+}
+
+int roar_init_visited_pool(roar_index *idx, uint32_t slots) {
+    if (!idx || idx->n == 0) return fail(ROAR_ERR_ARG, "InitVisitedListPool before the base vectors were loaded");
+    int e = use_device(idx);
+    if (e) return e;
+    return ensure_tags(idx, std::max<uint32_t>(slots, 1));
+}
+
+int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats,
+                             uint32_t k, uint32_t L_pq, uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev,
+                             uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
+                             void *hip_stream) {
+    if (!idx || !ids_dev || !dists_dev || (nq && !queries_dev)) return fail(ROAR_ERR_ARG, "bad search arguments");
+    if (nq == 0) return ROAR_OK;
+    if (qstride_floats < idx->dim_pad || (qstride_floats & 3))
+        return fail(ROAR_ERR_ARG, "device queries need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
+    int e = use_device(idx);
+    if (e) return e;
+    LaunchPlan plan;
+    if ((e = plan_search(idx, nq, k, L_pq, &plan))) return e;
+    RoarSearchParams &p = plan.p;
+    p.queries = queries_dev;
+    p.qstride = qstride_floats;
+    p.out_ids = ids_dev;
+    p.out_dists = dists_dev;
+    p.out_cmps = cmps_dev;
+    p.out_hops = hops_dev;
+    p.out_scanned = scanned_dev;
+    p.short_count = short_count_dev;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
+    if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(idx->ev0, st));
+    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->visited_mode, plan.grid, st);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipEventRecord(idx->ev1, st));
+    idx->ev_valid = true;
+    return ROAR_OK;
+}
+
+int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                      uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
+                      uint32_t *scanned) {
+    if (!idx || !ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
+    if (nq == 0) return ROAR_OK;
+    if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    int e = use_device(idx);
+    if (e) return e;
+    // stage queries padded to dim_pad (data_align of the query block, tests/test_search_roargraph.cpp:131)
+    const uint64_t qfloats = nq * idx->dim_pad;
+    if (idx->q_cap < qfloats) {
+        if (idx->q_dev) (void)hipFree(idx->q_dev);
+        idx->q_dev = nullptr;
+        HIP_TRY(hipMalloc((void **)&idx->q_dev, (size_t)qfloats * sizeof(float)));
+        idx->q_cap = qfloats;
+    }
+    const uint64_t owords = nq * (2ull * k + 3) + 1;
+    if (idx->out_cap < owords) {
+        if (idx->out_dev) (void)hipFree(idx->out_dev);
+        idx->out_dev = nullptr;
+        HIP_TRY(hipMalloc((void **)&idx->out_dev, (size_t)owords * sizeof(uint32_t)));
+        idx->out_cap = owords;
+    }
+    if (qstride_floats == idx->dim_pad) {
+        HIP_TRY(hipMemcpy(idx->q_dev, queries, (size_t)qfloats * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> buf((size_t)qfloats, 0.0f);
+        for (uint64_t i = 0; i < nq; ++i)
+            memcpy(buf.data() + i * idx->dim_pad, queries + i * qstride_floats,
+                   std::min<uint32_t>(qstride_floats, idx->dim_pad) * sizeof(float));
+        if (qstride_floats > idx->dim)  // anything past dim is padding and must read as zero
+            for (uint64_t i = 0; i < nq; ++i)
+                memset(buf.data() + i * idx->dim_pad + idx->dim, 0, (idx->dim_pad - idx->dim) * sizeof(float));
+        HIP_TRY(hipMemcpy(idx->q_dev, buf.data(), (size_t)qfloats * sizeof(float), hipMemcpyHostToDevice));
+    }
+    uint32_t *d_ids = idx->out_dev;
+    float *d_dists = reinterpret_cast<float *>(d_ids + nq * k);
+    uint32_t *d_cmps = d_ids + 2 * nq * k;
+    uint32_t *d_hops = d_cmps + nq;
+    uint32_t *d_scan = d_hops + nq;
+    uint32_t *d_short = d_scan + nq;
+    e = roar_search_batch_device(idx, idx->q_dev, nq, idx->dim_pad, k, L_pq, d_ids, d_dists, d_cmps, d_hops, d_scan,
+                                 d_short, nullptr);
+    if (e) return e;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dists, d_dists, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    if (cmps) HIP_TRY(hipMemcpy(cmps, d_cmps, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    if (hops) HIP_TRY(hipMemcpy(hops, d_hops, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    if (scanned) HIP_TRY(hipMemcpy(scanned, d_scan, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    uint32_t nshort = 0;
+    HIP_TRY(hipMemcpy(&nshort, d_short, 4, hipMemcpyDeviceToHost));
+    if (nshort) {
+        // message of the first short query, as the reference would have thrown it (:2408-2412)
+        for (uint64_t i = 0; i < nq; ++i) {
+            uint32_t have = 0;
+            while (have < k && ids[i * k + have] != 0xFFFFFFFFu) have++;
+            if (have < k) return fail(ROAR_ERR_SHORT, "not enough results: %u, expected: %u", have, k);
+        }
+        return fail(ROAR_ERR_SHORT, "not enough results");
+    }
+    return ROAR_OK;
+}
+
+int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, const uint32_t *ids,
+                   uint32_t m, float *out) {
+    if (!idx || !queries || !ids || !out) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (!idx->base) return fail(ROAR_ERR_ARG, "distances before base vectors were loaded");
+    if (nq == 0 || m == 0) return ROAR_OK;
+    if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    for (uint64_t i = 0; i < nq * m; ++i)
+        if (ids[i] >= idx->n) return fail(ROAR_ERR_ARG, "id %u outside the base set", ids[i]);
+    int e = use_device(idx);
+    if (e) return e;
+    float *q_dev = nullptr, *o_dev = nullptr;
+    uint32_t *i_dev = nullptr;
+    std::vector<float> buf((size_t)nq * idx->dim_pad, 0.0f);
+    for (uint64_t i = 0; i < nq; ++i)
+        memcpy(buf.data() + i * idx->dim_pad, queries + i * qstride_floats, idx->dim * sizeof(float));
+    HIP_TRY(hipMalloc((void **)&q_dev, buf.size() * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&i_dev, (size_t)nq * m * 4));
+    HIP_TRY(hipMalloc((void **)&o_dev, (size_t)nq * m * 4));
+    HIP_TRY(hipMemcpy(q_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(i_dev, ids, (size_t)nq * m * 4, hipMemcpyHostToDevice));
+    RoarDistParams p;
+    memset(&p, 0, sizeof p);
+    p.base = idx->base;
+    p.ld = idx->ld;
+    p.dim = idx->dim_pad;
+    p.queries = q_dev;
+    p.qstride = idx->dim_pad;
+    p.nq = (uint32_t)nq;
+    p.ids = i_dev;
+    p.m = m;
+    p.out = o_dev;
+    p.off_ck = 0;
+    p.off_cid = 8 * 64;
+    p.off_q = p.off_cid + 4 * 64;
+    p.lds_bytes = p.off_q + round_up(4 * idx->dim_pad, 16);
+    int rc = roar_launch_distances(&p, idx->ip ? 1 : 0, nullptr);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "distance kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, o_dev, (size_t)nq * m * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(q_dev);
+    (void)hipFree(i_dev);
+    (void)hipFree(o_dev);
+    return ROAR_OK;
+}
+
+int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
+                           const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream) {
+    if (nshards == 0 || nshards > 32 || k == 0) return fail(ROAR_ERR_ARG, "merge needs 1..32 shards and k > 0");
+    if (!ids_dev || !dists_dev || !out_ids_dev || !out_dists_dev) return fail(ROAR_ERR_ARG, "bad merge arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(ROAR_ERR_DEVICE, "no HIP device available; this library has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    int rc = roar_launch_merge_topk(nshards, nq, k, ids_dev, dists_dev, out_ids_dev, out_dists_dev, hip_stream);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "merge kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return ROAR_OK;
+}
+
+int roar_set_option(roar_index *idx, const char *key, int64_t value) {
+    if (!idx || !key) return fail(ROAR_ERR_ARG, "bad arguments");
+    std::string k(key);
+    if (k == "visited_mode") {
+        if (value != ROAR_VISITED_EXACT && value != ROAR_VISITED_LDS) return fail(ROAR_ERR_ARG, "bad visited_mode");
+        idx->visited_mode = (int)value;
+    } else if (k == "waves_per_cu") {
+        if (value < 0 || value > 32) return fail(ROAR_ERR_ARG, "waves_per_cu must be 0..32");
+        idx->waves_per_cu = (int)value;
+    } else if (k == "vis_entries") {
+        if (value < 0 || (value & (value - 1))) return fail(ROAR_ERR_ARG, "vis_entries must be 0 or a power of two");
+        idx->vis_entries = (int)value;
+    } else if (k == "max_grid") {
+        if (value < 0) return fail(ROAR_ERR_ARG, "max_grid must be >= 0");
+        idx->max_grid = (int)value;
+    } else {
+        return fail(ROAR_ERR_ARG, "Invalid parameter name.");  // parameters.h:28
+    }
+    return ROAR_OK;
+}
+
+int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
+    if (!idx || !key || !value) return fail(ROAR_ERR_ARG, "bad arguments");
+    std::string k(key);
+    if (k == "n") *value = (int64_t)idx->n;
+    else if (k == "dim") *value = idx->dim;
+    else if (k == "dim_padded") *value = idx->dim_pad;
+    else if (k == "ep") *value = idx->ep;
+    else if (k == "max_degree") *value = idx->max_deg;
+    else if (k == "nedges") *value = (int64_t)idx->nedges;
+    else if (k == "adj_stride") *value = idx->adj_stride;
+    else if (k == "row_stride") *value = idx->ld;
+    else if (k == "n_cus") *value = idx->n_cus;
+    else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
+    else if (k == "visited_mode") *value = idx->visited_mode;
+    else if (k == "last_grid") *value = idx->last_grid;
+    else if (k == "last_lds_bytes") *value = idx->last_lds;
+    else if (k == "last_vis_entries") *value = idx->last_vis_entries;
+    else if (k == "last_kernel_ns") {
+        if (!idx->ev_valid) return fail(ROAR_ERR_ARG, "no search has been launched yet");
+        HIP_TRY(hipSetDevice(idx->device));
+        HIP_TRY(hipEventSynchronize(idx->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+        *value = (int64_t)((double)ms * 1e6);
+    } else {
+        return fail(ROAR_ERR_ARG, "Invalid parameter name.");
+    }
+    return ROAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// roar_device.h -- launch-parameter block shared by the HIP kernels (roar_kernels.hip) and the
+// C-ABI host code (roar_capi.cpp).  Internal; the public boundary is include/roargraph_amd.h.
+#pragma once
+#include <stdint.h>
+
+struct RoarSearchParams {
+    // base vectors: f32 rows, `ld` floats apart, scored over `dim` floats (dim % 8 == 0, zero padded)
+    const float *base;
+    uint64_t ld;
+    uint32_t dim;
+    // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
+    const uint32_t *adj;
+    uint32_t adj_stride;
+    uint32_t n;
+    uint32_t ep;
+    // query batch
+    const float *queries;
+    uint64_t qstride;
+    uint32_t nq;
+    uint32_t k;
+    uint32_t L;
+    // outputs (cmps / hops / scanned / short_count may be null)
+    uint32_t *out_ids;
+    float *out_dists;
+    uint32_t *out_cmps;
+    uint32_t *out_hops;
+    uint32_t *out_scanned;
+    uint32_t *short_count;
+    // dynamic dequeue counter (zeroed before every launch)
+    uint32_t *counter;
+    // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
+    uint32_t vis_sets_log2;
+    // visited, EXACT mode: one u8[tag_stride] list per resident wave + its epoch
+    uint8_t *tags;
+    uint64_t tag_stride;
+    uint32_t *epochs;
+    // LDS carve-up (byte offsets, all 16-byte aligned)
+    uint32_t off_pool, off_ck, off_cid, off_q, off_vis, lds_bytes;
+};
+
+struct RoarDistParams {
+    const float *base;
+    uint64_t ld;
+    uint32_t dim;
+    const float *queries;
+    uint64_t qstride;
+    uint32_t nq;
+    const uint32_t *ids;  // [nq][m]
+    uint32_t m;
+    float *out;           // [nq][m]
+    uint32_t off_ck, off_cid, off_q, lds_bytes;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
+// visited_mode: 0 exact tags, 1 LDS table.  Returns a hipError_t value (0 = success).
+int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, uint32_t grid, void *stream);
+int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
+int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
+                           uint32_t *out_ids, float *out_dists, void *stream);
+// Max resident single-wave workgroups per CU for the search kernel variant at this LDS size.
+int roar_search_occupancy(int metric_ip, int visited_mode, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
+#ifdef __cplusplus
+}
+#endif

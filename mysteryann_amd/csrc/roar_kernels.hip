@@ -1,0 +1,468 @@
+// roar_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the RoarGraph beam search.
+//
+// One wavefront owns one query at a time (single-wave workgroups, persistent, dynamic dequeue),
+// so every piece of per-query state of the reference lives on-chip:
+//
+//   reference (CPU)                                   here (per wave)
+//   ------------------------------------------------  ---------------------------------------------
+//   NeighborPriorityQueue  neighbor.h:138-223         sorted u64 keys in LDS  (ord(dist)<<32 | id<<1 | expanded)
+//   VisitedList            visited_list_pool.h:8-29   LDS 4-way u16 tag table (mode LDS) or u8 epoch tags in HBM (mode EXACT)
+//   projection_graph_[v]   index_bipartite.h:150      one coalesced read of a fixed-stride adjacency row
+//   distance_->compare     distance.h:39-89,179-223   16 rows per pass, 4 lanes per row, 64-B pieces, fmaf chains
+//   SearchRoarGraph loop   index_bipartite.cpp:2356-2405  select -> adjacency -> visited filter -> score -> merge
+//
+// Distances are bit-identical to the reference's AVX-512 code as gcc builds it (-Ofast contracts
+// every mul+add to vfmadd231ps): lane t of a 4-lane group holds SIMD lanes 4t..4t+3 of the
+// reference's zmm accumulator and walks the row in the same 16-float steps, then the
+// 16->8->4->hadd reduction tree is replayed with quad DPP moves.  Bit-identical distances make the
+// (distance, id) order, hence every expansion and every returned id, identical to the CPU path.
+//
+// The kernel is HBM-gather bound (0.5 flop/byte): nothing here goes through MFMA on purpose.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "roar_device.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+// LDS traffic between lanes of one wave: the LDS executes a wave's instructions in order, the
+// fences only stop the compiler from reordering across the hand-off.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 lane_u64(u64 v, int l) {
+    uint32_t lo = lane_u32((uint32_t)v, l), hi = lane_u32((uint32_t)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t lanes_below(u64 mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// float <-> order-preserving u32 (so that one u64 compare is Neighbor::operator<, neighbor.h:29-31)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    if (f == 0.0f) f = 0.0f;  // -0.0 == +0.0 for operator<
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o >> 31) ? (o ^ 0x80000000u) : ~o);
+}
+__device__ __forceinline__ u64 make_key(float d, uint32_t id) { return ((u64)f2ord(d) << 32) | ((u64)id << 1); }
+
+// quad DPP: value of lane (l ^ 2) / (l ^ 1) inside each 4-lane group
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+template <bool IP>
+__device__ __forceinline__ void acc16(float4 &acc, const float4 x, const float4 y) {
+    if (IP) {  // distance.h:187  msum0 += mx * my  (fma)
+        acc.x = __builtin_fmaf(x.x, y.x, acc.x);
+        acc.y = __builtin_fmaf(x.y, y.y, acc.y);
+        acc.z = __builtin_fmaf(x.z, y.z, acc.z);
+        acc.w = __builtin_fmaf(x.w, y.w, acc.w);
+    } else {  // distance.h:47-48  d = mx - my; msum0 += d * d
+        float a = x.x - y.x, b = x.y - y.y, c = x.z - y.z, d = x.w - y.w;
+        acc.x = __builtin_fmaf(a, a, acc.x);
+        acc.y = __builtin_fmaf(b, b, acc.y);
+        acc.z = __builtin_fmaf(c, c, acc.z);
+        acc.w = __builtin_fmaf(d, d, acc.w);
+    }
+}
+
+// One base row against the query held in LDS, by the 4 lanes of a group (t = lane & 3).
+// NCH > 0: number of full 16-float steps known at compile time (all loads issued up front);
+// NCH == 0: runtime dim, 8 steps in flight at a time.
+template <bool IP, int NCH>
+__device__ __forceinline__ float row_distance(const float *__restrict__ rowp, const float *lq, uint32_t dim, int t) {
+    const float4 *row = reinterpret_cast<const float4 *>(rowp) + t;
+    const float4 *q4 = reinterpret_cast<const float4 *>(lq) + t;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t done;
+    if (NCH > 0) {
+        float4 x[NCH > 0 ? NCH : 1];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) x[i] = row[4 * i];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) acc16<IP>(acc, x[i], q4[4 * i]);
+        done = NCH;
+    } else {
+        const uint32_t nfull = dim >> 4;
+        uint32_t c = 0;
+        for (; c + 8 <= nfull; c += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = row[4 * (c + i)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc16<IP>(acc, x[i], q4[4 * (c + i)]);
+        }
+        for (; c < nfull; ++c) acc16<IP>(acc, row[4 * c], q4[4 * c]);
+        done = nfull;
+    }
+    // 16 -> 8 (distance.h:52-53 / :191-192): lanes t and t^2 now both hold s1[4*(t&1) .. +3]
+    float4 s1;
+    s1.x = quad_xor2(acc.x) + acc.x;
+    s1.y = quad_xor2(acc.y) + acc.y;
+    s1.z = quad_xor2(acc.z) + acc.z;
+    s1.w = quad_xor2(acc.w) + acc.w;
+    if (dim & 8) {  // one 8-float step (distance.h:55-63 / :194-201)
+        const float4 *rt = reinterpret_cast<const float4 *>(rowp) + 4 * done + (t & 1);
+        const float4 *qt = reinterpret_cast<const float4 *>(lq) + 4 * done + (t & 1);
+        acc16<IP>(s1, *rt, *qt);
+    }
+    // 8 -> 4 (:65-66 / :203-204), then the two hadd (:85-86 / :221-222)
+    float a = quad_xor1(s1.x) + s1.x;
+    float b = quad_xor1(s1.y) + s1.y;
+    float c2 = quad_xor1(s1.z) + s1.z;
+    float d = quad_xor1(s1.w) + s1.w;
+    float r = (a + b) + (c2 + d);
+    return IP ? -r : r;  // distance.h:223
+}
+
+// Score cid[0..m) against the query; ck[i] = key(distance, id).  16 rows per pass.
+template <bool IP, int NCH>
+__device__ __forceinline__ void score_candidates(const float *__restrict__ base, uint64_t ld, uint32_t dim,
+                                                 const float *lq, const uint32_t *cid, u64 *ck, uint32_t m,
+                                                 int lane) {
+    const int t = lane & 3, g = lane >> 2;
+    for (uint32_t p0 = 0; p0 < m; p0 += 16) {
+        const uint32_t c = p0 + g;
+        if (c < m) {  // whole 4-lane groups are active or idle together
+            const uint32_t id = cid[c];
+            const float d = row_distance<IP, NCH>(base + (u64)id * ld, lq, dim, t);
+            if (t == 0) ck[c] = make_key(d, id);
+        }
+    }
+}
+
+// NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of m <= 64 candidates at once.
+// Sequential inserts keep the top-L of everything seen; so does this merge, entry for entry.
+// Duplicate (distance, id) pairs are dropped exactly as the binary-search probe does (:161-162).
+__device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m, uint32_t L, uint32_t &psize,
+                                                 uint32_t &cur, int lane) {
+    const u64 FLAG = 1ull;
+    bool valid = (uint32_t)lane < m;
+    u64 key = valid ? ck[lane] : ~0ull;
+    if (psize == L) {  // neighbor.h:151-153
+        const u64 last = pool[L - 1] & ~FLAG;
+        valid = valid && key < last;
+    }
+    if (__ballot(valid) == 0) return;
+    // lower bound of key among the (flag-masked) pool keys
+    uint32_t lo = 0;
+    {
+        uint32_t len = psize;
+        const int iters = 32 - __builtin_clz(psize);  // psize >= 1
+        for (int it = 0; it < iters; ++it) {
+            if (len > 0) {
+                const uint32_t half = len >> 1, mid = lo + half;
+                const bool less = (pool[mid] & ~FLAG) < key;
+                lo = less ? mid + 1 : lo;
+                len = less ? len - half - 1 : half;
+            }
+        }
+    }
+    if (valid && lo < psize && (pool[lo] & ~FLAG) == key) valid = false;  // already in the pool
+    // rank among the surviving candidates; a later lane with an equal key is a duplicate
+    uint32_t r = 0;
+    for (u64 it = __ballot(valid); it;) {
+        const int j = __ffsll((long long)it) - 1;
+        it &= it - 1;
+        if (!((__ballot(valid) >> j) & 1)) continue;
+        const u64 kj = lane_u64(key, j);
+        if (valid && j != lane) {
+            if (kj < key) r++;
+            else if (kj == key && j < lane) valid = false;
+        }
+    }
+    const u64 vm = __ballot(valid);
+    if (vm == 0) return;
+    const uint32_t s = (uint32_t)__popcll(vm);
+    const int l0 = __ffsll((long long)__ballot(valid && r == 0)) - 1;
+    const uint32_t pmin = lane_u32(lo, l0);
+    // shift pool[pmin, psize) right, top chunk first (a chunk never lands below its own start)
+    for (uint32_t hi = psize; hi > pmin;) {
+        const uint32_t lo_c = (hi - pmin > 64u) ? hi - 64u : pmin;
+        const uint32_t kidx = lo_c + (uint32_t)lane;
+        const bool act = kidx < hi;
+        const u64 e = act ? pool[kidx] : 0ull;
+        uint32_t shift = 0;
+        for (u64 it = vm; it;) {
+            const int j = __ffsll((long long)it) - 1;
+            it &= it - 1;
+            shift += (lane_u32(lo, j) <= kidx) ? 1u : 0u;
+        }
+        wave_sync();
+        if (act && kidx + shift < L) pool[kidx + shift] = e;
+        wave_sync();
+        hi = lo_c;
+    }
+    if (valid && lo + r < L) pool[lo + r] = key;
+    psize = (psize + s < L) ? psize + s : L;
+    cur = cur < pmin ? cur : pmin;  // neighbor.h:180-182
+    wave_sync();
+}
+
+constexpr int VIS_EXACT = 0;
+constexpr int VIS_LDS = 1;
+
+template <int MODE, bool IP, int NCH>
+__global__ void __launch_bounds__(64, 4) roar_search_kernel(const RoarSearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck);
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
+    const uint32_t L = p.L;
+    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
+    uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
+
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(p.counter, 1u);
+        q = uni(q);
+        if (q >= p.nq) break;
+
+        // query -> LDS (tests/test_search_roargraph.cpp:205 passes aligned_query_data + i * q_dim)
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = lane * 4; i < p.dim; i += 256)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        if (MODE == VIS_LDS) {  // fresh visited table
+            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
+            for (uint32_t i = lane; i < n16; i += 64) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
+        } else {  // VisitedList::reset (visited_list_pool.h:20-26) with a u8 epoch
+            epoch++;
+            if (epoch == 256u) {
+                for (u64 i = (u64)lane * 16; i < p.tag_stride; i += 1024)
+                    *reinterpret_cast<uint4 *>(tags + i) = make_uint4(0, 0, 0, 0);
+                __threadfence();
+                epoch = 1;
+            }
+        }
+        // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
+        if (lane == 0) cid[0] = p.ep;
+        wave_sync();
+        score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, 1, lane);
+        wave_sync();
+        if (lane == 0) pool[0] = ck[0];
+        wave_sync();
+        uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
+
+        while (cur < psize) {  // has_unexpanded_node, :2356
+            // closest_unexpanded (neighbor.h:185-192): flag the entry, move the cursor past flagged ones
+            const u64 e = pool[cur];
+            const uint32_t v = (uint32_t)e >> 1;
+            if (lane == 0) pool[cur] = e | 1ull;
+            wave_sync();
+            {
+                uint32_t found = psize;
+                for (uint32_t c = cur + 1; c < psize; c += 64) {
+                    const uint32_t kidx = c + (uint32_t)lane;
+                    const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                    const u64 b = __ballot(unf);
+                    if (b) {
+                        found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                        break;
+                    }
+                }
+                cur = found;
+            }
+            ++hops;
+            // adjacency row: word 0 = degree, word w (>= 1) = neighbour w - 1; 64 words per chunk
+            const uint32_t *arow = p.adj + (u64)v * p.adj_stride;
+            uint32_t word = arow[lane];
+            const uint32_t deg = uni(word);
+            scanned += deg;
+            for (uint32_t w0 = 0; w0 <= deg; w0 += 64) {
+                if (w0) word = arow[w0 + lane];
+                const uint32_t w = w0 + (uint32_t)lane;
+                const bool isnbr = w >= 1 && w <= deg;
+                const uint32_t nb = isnbr ? word : 0u;
+                bool fresh;
+                if (MODE == VIS_LDS) {
+                    // 4-way set of u16 tags; (set, tag) <-> id is a bijection, so a hit is never false.
+                    // The table may forget (way overwritten): the node is then scored again and the
+                    // duplicate key is dropped by the merge, results are unchanged.
+                    const uint32_t set = nb & sets_mask;
+                    const uint32_t tag = (nb >> p.vis_sets_log2) + 1u;
+                    const uint2 ww = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+                    const uint32_t t0 = ww.x & 0xFFFFu, t1 = ww.x >> 16, t2 = ww.y & 0xFFFFu, t3 = ww.y >> 16;
+                    const bool hit = (t0 == tag) | (t1 == tag) | (t2 == tag) | (t3 == tag);
+                    fresh = isnbr && !hit;
+                    if (fresh) {
+                        const uint32_t way = t0 == 0 ? 0u : t1 == 0 ? 1u : t2 == 0 ? 2u : t3 == 0 ? 3u : (tag & 3u);
+                        vis[4 * set + way] = (uint16_t)tag;
+                    }
+                } else {  // visited_array[nbr] != tag ... = tag  (index_bipartite.cpp:2378,2385)
+                    uint32_t tg = 0;
+                    if (isnbr) tg = __builtin_nontemporal_load(tags + nb);
+                    fresh = isnbr && tg != epoch;
+                    if (fresh) __builtin_nontemporal_store((uint8_t)epoch, tags + nb);
+                }
+                const u64 fm = __ballot(fresh);
+                const uint32_t m = (uint32_t)__popcll(fm);
+                if (m == 0) continue;
+                if (fresh) cid[lanes_below(fm)] = nb;
+                cmps += m;  // ++cmps per scored neighbour, :2397
+                wave_sync();
+                score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, m, lane);
+                wave_sync();
+                merge_candidates(pool, ck, m, L, psize, cur, lane);
+            }
+        }
+
+        // results (:2408-2418); a short pool is reported, not thrown
+        for (uint32_t i = lane; i < p.k; i += 64) {
+            uint32_t id = 0xFFFFFFFFu;
+            float d = __builtin_inff();
+            if (i < psize) {
+                const u64 e = pool[i];
+                id = (uint32_t)e >> 1;
+                d = ord2f((uint32_t)(e >> 32));
+            }
+            p.out_ids[(u64)q * p.k + i] = id;
+            p.out_dists[(u64)q * p.k + i] = d;
+        }
+        if (lane == 0) {
+            if (p.out_cmps) p.out_cmps[q] = cmps;
+            if (p.out_hops) p.out_hops[q] = hops;
+            if (p.out_scanned) p.out_scanned[q] = scanned;
+            if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+        }
+        wave_sync();
+    }
+    if (MODE == VIS_EXACT && lane == 0) p.epochs[blockIdx.x] = epoch;
+}
+
+// distance-only kernel: one wave per query, m explicit ids each (parity surface for A2/A3)
+template <bool IP>
+__global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck);
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = lane * 4; i < p.dim; i += 256)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        for (uint32_t c0 = 0; c0 < p.m; c0 += 64) {
+            const uint32_t mm = (p.m - c0 < 64u) ? p.m - c0 : 64u;
+            if ((uint32_t)lane < mm) cid[lane] = p.ids[(u64)q * p.m + c0 + lane];
+            wave_sync();
+            score_candidates<IP, 0>(p.base, p.ld, p.dim, lq, cid, ck, mm, lane);
+            wave_sync();
+            if ((uint32_t)lane < mm) p.out[(u64)q * p.m + c0 + lane] = ord2f((uint32_t)(ck[lane] >> 32));
+            wave_sync();
+        }
+    }
+}
+
+// k-way merge of per-shard sorted top-k lists by (distance, id); one thread per query.
+__global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, const uint32_t *__restrict__ ids,
+                                       const float *__restrict__ dists, uint32_t *__restrict__ out_ids,
+                                       float *__restrict__ out_dists) {
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t head[32];
+    for (uint32_t s = 0; s < nshards; ++s) head[s] = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        u64 best = ~0ull;
+        uint32_t bs = 0xFFFFFFFFu;
+        for (uint32_t s = 0; s < nshards; ++s) {
+            if (head[s] >= k) continue;
+            const u64 off = ((u64)s * nq + q) * k + head[s];
+            const uint32_t id = ids[off];
+            if (id == 0xFFFFFFFFu) {
+                head[s] = k;
+                continue;
+            }
+            const u64 key = ((u64)f2ord(dists[off]) << 32) | id;
+            if (key < best) {
+                best = key;
+                bs = s;
+            }
+        }
+        if (bs == 0xFFFFFFFFu) {
+            out_ids[q * k + i] = 0xFFFFFFFFu;
+            out_dists[q * k + i] = __builtin_inff();
+        } else {
+            const u64 off = ((u64)bs * nq + q) * k + head[bs];
+            out_ids[q * k + i] = ids[off];
+            out_dists[q * k + i] = dists[off];
+            head[bs]++;
+        }
+    }
+}
+
+template <int MODE, bool IP>
+const void *pick_nch(uint32_t dim) {
+    switch (dim >> 4) {
+        case 8: return (const void *)roar_search_kernel<MODE, IP, 8>;    // D = 128 (136)
+        case 12: return (const void *)roar_search_kernel<MODE, IP, 12>;  // D = 200 (192)
+        default: return (const void *)roar_search_kernel<MODE, IP, 0>;
+    }
+}
+
+const void *pick_kernel(int metric_ip, int visited_mode, uint32_t dim) {
+    if (visited_mode == VIS_EXACT)
+        return metric_ip ? pick_nch<VIS_EXACT, true>(dim) : pick_nch<VIS_EXACT, false>(dim);
+    return metric_ip ? pick_nch<VIS_LDS, true>(dim) : pick_nch<VIS_LDS, false>(dim);
+}
+
+}  // namespace
+
+extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, uint32_t grid,
+                                  void *stream) {
+    const void *fn = pick_kernel(metric_ip, visited_mode, p->dim);
+    if (p->lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    RoarSearchParams params = *p;
+    void *args[] = {&params};
+    return (int)hipLaunchKernel(fn, dim3(grid), dim3(64), args, p->lds_bytes, (hipStream_t)stream);
+}
+
+extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, uint32_t dim, uint32_t lds_bytes,
+                                     int *blocks_per_cu) {
+    const void *fn = pick_kernel(metric_ip, visited_mode, dim);
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 64, lds_bytes);
+}
+
+extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {
+    uint32_t grid = p->nq < 4096u ? p->nq : 4096u;
+    if (grid == 0) return 0;
+    if (metric_ip)
+        hipLaunchKernelGGL(roar_distance_kernel<true>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
+    else
+        hipLaunchKernelGGL(roar_distance_kernel<false>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids,
+                                      const float *dists, uint32_t *out_ids, float *out_dists, void *stream) {
+    if (nq == 0) return 0;
+    const uint32_t block = 256;
+    const uint32_t grid = (uint32_t)((nq + block - 1) / block);
+    hipLaunchKernelGGL(roar_merge_topk_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, nshards, (u64)nq, k, ids,
+                       dists, out_ids, out_dists);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,194 @@
+"""Python mirror of the reference's operator interface for the search path -- same names and
+argument meaning as efanna2e::IndexBipartite (include/index_bipartite.h) and efanna2e::Parameters
+(include/efanna2e/parameters.h), so that the parity tests read like the reference's harness
+(tests/test_search_roargraph.cpp:160-209).  Every method is a thin call into the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import METRIC_COSINE, METRIC_IP, METRIC_L2, RoarError  # noqa: F401
+
+L2, INNER_PRODUCT, COSINE = METRIC_L2, METRIC_IP, METRIC_COSINE  # efanna2e::Metric, distance.h:15
+
+
+class Parameters:
+    """efanna2e::Parameters (parameters.h:15-57): string-valued map with typed Get."""
+
+    def __init__(self):
+        self._p = {}
+
+    def Set(self, name, value):
+        self._p[name] = str(value)
+
+    def Get(self, name, typ=int, default=None):
+        if name not in self._p:
+            if default is not None:
+                return default
+            raise ValueError("Invalid parameter name.")  # std::invalid_argument, parameters.h:28
+        try:
+            return typ(self._p[name])
+        except ValueError as e:
+            raise RuntimeError(f"Failed to convert value '{self._p[name]}' to type: {typ.__name__}") from e
+
+
+class IndexBipartite:
+    """efanna2e::IndexBipartite restricted to the RoarGraph search path.
+
+    IndexBipartite(dimension, n, metric, initializer)   src/index_bipartite.cpp:30-38
+    """
+
+    def __init__(self, dimension, n=0, metric=L2, initializer=None, device=0):
+        self._h = C.c_void_p()
+        self._lib = capi.lib()
+        capi.check(self._lib.roar_create(C.byref(self._h), int(dimension), int(metric), int(device)))
+        self.dimension = int(dimension)
+        self.metric = int(metric)
+        self.device = int(device)
+        self.need_normalize = metric == COSINE  # index_bipartite.h:145, set at index_bipartite.cpp:35-37
+        self._keep = []  # device tensors adopted by reference
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.roar_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- load ---------------------------------------------------------------------------------
+    def LoadSearchNeededData(self, base_file, sampled_query_file=""):
+        """index_bipartite.h:62-64 -> LoadVectorData (index_bipartite.cpp:2661-2692)."""
+        capi.check(self._lib.roar_load_base_fbin(self._h, str(base_file).encode()))
+
+    def SetBaseData(self, rows):
+        """Same as LoadSearchNeededData from memory: numpy [n, dim] (host) or a CUDA/HIP torch tensor
+        [n, stride] already zero padded to a multiple of 8 floats (adopted without a copy)."""
+        if isinstance(rows, np.ndarray):
+            rows = np.ascontiguousarray(rows, np.float32)
+            capi.check(self._lib.roar_set_base(self._h, capi.f32p(rows), rows.shape[0], rows.shape[1]))
+        else:  # torch tensor on the device
+            assert rows.is_cuda and rows.dtype.is_floating_point and rows.element_size() == 4 and rows.is_contiguous()
+            self._keep.append(rows)
+            capi.check(self._lib.roar_set_base_device(self._h, C.c_void_p(rows.data_ptr()), rows.shape[0],
+                                                      rows.shape[1]))
+
+    def LoadProjectionGraph(self, filename):
+        """index_bipartite.cpp:2097-2117"""
+        capi.check(self._lib.roar_load_graph_file(self._h, str(filename).encode()))
+
+    def SetProjectionGraph(self, ep, offsets, nbrs):
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        if nbrs.size == 0:
+            nbrs = np.zeros(1, np.uint32)
+        capi.check(self._lib.roar_set_graph_csr(self._h, int(ep), len(offsets) - 1, capi.u64p(offsets),
+                                                capi.u32p(nbrs)))
+
+    def SaveProjectionGraph(self, filename):
+        """index_bipartite.cpp:2606-2619"""
+        capi.check(self._lib.roar_save_graph_file(self._h, str(filename).encode()))
+
+    def GetProjectionGraph(self):
+        ep, n, ne = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        capi.check(self._lib.roar_get_graph_csr(self._h, C.byref(ep), C.byref(n), C.byref(ne), None, None))
+        offsets = np.zeros(n.value + 1, np.uint64)
+        nbrs = np.zeros(max(ne.value, 1), np.uint32)
+        capi.check(self._lib.roar_get_graph_csr(self._h, None, None, None, capi.u64p(offsets), capi.u32p(nbrs)))
+        return ep.value, offsets, nbrs[:ne.value]
+
+    def InitVisitedListPool(self, num_threads):
+        """index_bipartite.h:133"""
+        capi.check(self._lib.roar_init_visited_pool(self._h, int(num_threads)))
+
+    # ---- options --------------------------------------------------------------------------------
+    def set_option(self, key, value):
+        capi.check(self._lib.roar_set_option(self._h, key.encode(), int(value)))
+
+    def info(self, key):
+        v = C.c_int64()
+        capi.check(self._lib.roar_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # ---- search ---------------------------------------------------------------------------------
+    def SearchRoarGraph(self, query, k, qid, parameters, indices=None, res_dists=None):
+        """index_bipartite.cpp:2311-2420 for ONE query; returns (cmps, hops) like the reference and
+        fills indices[k] / res_dists[k] when given.  A batch of one through the same kernel."""
+        L = parameters.Get("L_pq", int)
+        r = self.SearchRoarGraphBatch(np.asarray(query, np.float32).reshape(1, -1), k, L)
+        if indices is not None:
+            indices[:k] = r["ids"][0]
+        if res_dists is not None:
+            res_dists[:k] = r["dists"][0]
+        return int(r["cmps"][0]), int(r["hops"][0])
+
+    def SearchRoarGraphBatch(self, queries, k, L_pq):
+        """All queries in one launch (host buffers).  -> dict(ids, dists, cmps, hops, scanned)."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        nq, qs = queries.shape
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        cmps = np.zeros(nq, np.uint32)
+        hops = np.zeros(nq, np.uint32)
+        scanned = np.zeros(nq, np.uint32)
+        rc = self._lib.roar_search_batch(self._h, capi.f32p(queries), nq, qs, int(k), int(L_pq), capi.u32p(ids),
+                                         capi.f32p(dists), capi.u32p(cmps), capi.u32p(hops), capi.u32p(scanned))
+        if rc == capi.ERR_SHORT:  # the reference throws std::runtime_error here (:2408-2412)
+            raise RoarError(rc, self._lib.roar_last_error().decode())
+        capi.check(rc)
+        return dict(ids=ids, dists=dists, cmps=cmps, hops=hops, scanned=scanned)
+
+    def SearchRoarGraphBatchDevice(self, queries, k, L_pq, out=None, stream=None):
+        """Device-resident form: `queries` is a CUDA/HIP torch tensor [nq, stride>=dim_padded];
+        results are torch tensors in HBM; asynchronous on `stream` (torch stream or None)."""
+        import torch
+
+        nq = queries.shape[0]
+        dev = queries.device
+        if out is None:
+            out = dict(ids=torch.empty((nq, k), dtype=torch.int32, device=dev),
+                       dists=torch.empty((nq, k), dtype=torch.float32, device=dev),
+                       cmps=torch.empty(nq, dtype=torch.int32, device=dev),
+                       hops=torch.empty(nq, dtype=torch.int32, device=dev),
+                       scanned=torch.empty(nq, dtype=torch.int32, device=dev),
+                       short=torch.zeros(1, dtype=torch.int32, device=dev))
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        capi.check(self._lib.roar_search_batch_device(
+            self._h, C.c_void_p(queries.data_ptr()), nq, queries.shape[1], int(k), int(L_pq),
+            C.c_void_p(out["ids"].data_ptr()), C.c_void_p(out["dists"].data_ptr()),
+            C.c_void_p(out["cmps"].data_ptr()), C.c_void_p(out["hops"].data_ptr()),
+            C.c_void_p(out["scanned"].data_ptr()), C.c_void_p(out["short"].data_ptr()),
+            C.c_void_p(st.cuda_stream)))
+        return out
+
+    def Distances(self, queries, ids):
+        """distance_->compare(base[id], query, dim) for explicit ids [nq, m] (distance.h:39-89,179-223)."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros(ids.shape, np.float32)
+        capi.check(self._lib.roar_distances(self._h, capi.f32p(queries), queries.shape[0], queries.shape[1],
+                                            capi.u32p(ids), ids.shape[1], capi.f32p(out)))
+        return out
+
+
+def ComputeRecall(res, gt, k):
+    """tests/test_search_roargraph.cpp:23-36: |gt[:k] in res[:k]| / (k * nq)."""
+    res = np.asarray(res)[:, :k].astype(np.int64)
+    gt = np.asarray(gt)[:, :k].astype(np.int64)
+    hit = (gt[:, :, None] == res[:, None, :]).any(axis=2).sum()
+    return float(hit) / float(k * res.shape[0])
+
+
+def normalize(arr):
+    """util.h:214-225 applied to every row (float32 sequential sum)."""
+    arr = np.array(arr, np.float32, copy=True)
+    for i in range(arr.shape[0]):
+        s = np.float32(0)
+        for v in arr[i]:
+            s = np.float32(s + v * v)
+        arr[i] = arr[i] / np.sqrt(s, dtype=np.float32)
+    return arr

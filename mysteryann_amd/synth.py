@@ -1,0 +1,97 @@
+"""Synthetic data of the shapes BASELINE.json names (no dataset can be downloaded).
+
+Recipes follow SURVEY.md section 8(d); they only fix shapes, scales and the base/query
+distribution shift (out-of-distribution queries, as in cross-modal data):
+
+  T2I shape   base  x = z A + 0.3 eps,   z ~ N(0, I_32), A in R^{32 x D} fixed, D = 200, IP,
+              query q = (1.5 z' + 0.5) B + 0.1 eps,  B = A + 0.5 Delta, scaled so |ip| <~ 1
+  SIFT shape  |N(0,1)| * 40 rounded and clipped to 0..255, D = 128, L2 (prepare_data.sh ranges)
+  WebVid shape unit-norm rows (prepare_for_clip_webvid.py:92-98), D = 512, IP / cosine
+
+`numpy` versions make the small fixtures; `torch` versions generate the full-size sets directly
+in HBM on the GPU box (torch is plumbing here: RNG + device memory).
+"""
+import numpy as np
+
+LATENT = 32
+
+
+def _maps(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((LATENT, d)).astype(np.float32)
+    Delta = rng.standard_normal((LATENT, d)).astype(np.float32)
+    B = (A + 0.5 * Delta).astype(np.float32)
+    # scale: E|x|^2 ~ LATENT*d*sA^2 ; choose so typical |<x,q>| is O(1)
+    s = np.float32(0.3 / np.sqrt(LATENT * np.sqrt(d)))
+    return A * s, B * s, s
+
+
+def t2i_numpy(n, nq, d=200, seed=1234, n_learn=0):
+    A, B, s = _maps(d, seed)
+    rng = np.random.default_rng(seed + 1)
+    base = (rng.standard_normal((n, LATENT)).astype(np.float32) @ A
+            + np.float32(0.3) * s * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+
+    def queries(m, r):
+        z = np.float32(1.5) * r.standard_normal((m, LATENT)).astype(np.float32) + np.float32(0.5)
+        return (z @ B + np.float32(0.1) * s * r.standard_normal((m, d)).astype(np.float32)).astype(np.float32)
+
+    q = queries(nq, np.random.default_rng(seed + 2))
+    learn = queries(n_learn, np.random.default_rng(seed + 3)) if n_learn else None
+    return base, q, learn
+
+
+def sift_numpy(n, nq, d=128, seed=1234, n_learn=0):
+    rng = np.random.default_rng(seed)
+    centers = np.abs(rng.standard_normal((64, d))).astype(np.float32) * 40
+
+    def draw(m, r):
+        c = centers[r.integers(0, 64, m)]
+        x = c + np.abs(r.standard_normal((m, d))).astype(np.float32) * 20
+        return np.clip(np.rint(x), 0, 255).astype(np.float32)
+
+    base = draw(n, np.random.default_rng(seed + 1))
+    q = draw(nq, np.random.default_rng(seed + 2))
+    learn = draw(n_learn, np.random.default_rng(seed + 3)) if n_learn else None
+    return base, q, learn
+
+
+def webvid_numpy(n, nq, d=512, seed=1234, n_learn=0):
+    base, q, learn = t2i_numpy(n, nq, d, seed, n_learn)
+
+    def unit(x):
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    return unit(base), unit(q), (unit(learn) if learn is not None else None)
+
+
+def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, row_stride=None):
+    """Full-size T2I-shape set generated in HBM.  Returns (base [n, row_stride], queries [nq, d], learn|None)."""
+    import torch
+
+    A, B, s = _maps(d, seed)
+    A = torch.from_numpy(A).to(device)
+    B = torch.from_numpy(B).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1)
+    ld = row_stride or d
+    base = torch.zeros((n, ld), dtype=torch.float32, device=device)
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        z = torch.randn((m, LATENT), generator=g, device=device)
+        e = torch.randn((m, d), generator=g, device=device)
+        base[i:i + m, :d] = z @ A + (0.3 * float(s)) * e
+
+    def queries(m, sd):
+        g.manual_seed(sd)
+        out = torch.empty((m, d), dtype=torch.float32, device=device)
+        for i in range(0, m, chunk):
+            mm = min(chunk, m - i)
+            z = 1.5 * torch.randn((mm, LATENT), generator=g, device=device) + 0.5
+            e = torch.randn((mm, d), generator=g, device=device)
+            out[i:i + mm] = z @ B + (0.1 * float(s)) * e
+        return out
+
+    q = queries(nq, seed + 2)
+    learn = queries(n_learn, seed + 3) if n_learn else None
+    return base, q, learn

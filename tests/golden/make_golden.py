@@ -1,0 +1,121 @@
+"""Generates the committed golden fixtures under tests/golden/ from the REFERENCE's own components.
+
+Run in the build container only (needs /root/reference and oracle/_ref/libroar_ref.so, i.e.
+`make -C oracle`):   python tests/golden/make_golden.py
+
+Everything written is data: synthetic inputs (seeded numpy), a graph index built by
+tests/golden/small_builder.py in the reference's on-disk format, brute-force ground truth, and the
+outputs of oracle/_ref -- the reference's DistanceL2 / DistanceInnerProduct, NeighborPriorityQueue,
+VisitedListPool and util.h loaders compiled where they lie -- on those inputs.  No reference source
+text is stored.
+
+Files per search case <name> in {l2_128, ip_200, cos_512}:
+  <name>.base.fbin  <name>.query.fbin  <name>.roar.index  <name>.gt.ibin
+  <name>.expected.npz : for L in LS: ids_L, dists_L, cmps_L, hops_L, scanned_L  (k = 10)
+distance_kat.npz : a_D, b_D, l2_D, ip_D for D in KAT_DIMS (128 pairs each)
+pq_trace.npz     : capacity, ops, ids, dists, snap (state after every op)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+import oracle  # noqa: E402
+from mysteryann_amd import fileio, synth  # noqa: E402
+from tests.golden import small_builder as sb  # noqa: E402
+
+LS = [10, 20, 50, 100, 200]
+K = 10
+KAT_DIMS = [8, 12, 20, 128, 200, 512]
+CASES = {
+    # name: (generator, metric, n, nq, d)
+    "l2_128": (synth.sift_numpy, oracle.METRIC_L2, 2000, 64, 128),
+    "ip_200": (synth.t2i_numpy, oracle.METRIC_IP, 2000, 64, 200),
+    "cos_512": (synth.webvid_numpy, oracle.METRIC_COSINE, 800, 48, 512),
+}
+
+
+def make_case(name):
+    gen, metric, n, nq, d = CASES[name]
+    base, q, learn = gen(n, nq, d, seed=1234, n_learn=n)
+    ep, adj = sb.build_roar_like(base, learn, metric, M_sq=32, M=16)
+    pre = os.path.join(HERE, name)
+    fileio.write_fbin(pre + ".base.fbin", base)
+    fileio.write_fbin(pre + ".query.fbin", q)
+    fileio.write_graph(pre + ".roar.index", ep, adj)
+    gt_ids, gt_d = sb.exact_knn(q, base, 100, metric)
+    fileio.write_gt(pre + ".gt.ibin", gt_ids, gt_d)
+    # the reference's loaders read the files back (load_meta / load_data / data_align)
+    base_l, _ = oracle.fbin_load_padded(pre + ".base.fbin", impl="ref")
+    q_l, _ = oracle.fbin_load_padded(pre + ".query.fbin", impl="ref")
+    ep2, off, nbrs = oracle.graph_load(pre + ".roar.index")
+    assert ep2 == ep
+    out = {}
+    for L in LS:
+        r = oracle.search_batch(base_l, off, nbrs, ep, q_l, K, L, metric, threads=4, impl="ref")
+        assert r["short"] == 0
+        for key in ("ids", "dists", "cmps", "hops", "scanned"):
+            out[f"{key}_{L}"] = r[key]
+        print(name, "L", L, "recall@10", round(oracle.recall(r["ids"], gt_ids, K), 4), "cmps", r["cmps"].mean(),
+              "hops", r["hops"].mean())
+    np.savez_compressed(pre + ".expected.npz", **out)
+
+
+def make_distance_kat():
+    rng = np.random.default_rng(99)
+    out = {}
+    for d in KAT_DIMS:
+        a = (rng.standard_normal((128, d)) * rng.choice([0.05, 1.0, 30.0], (128, 1))).astype(np.float32)
+        b = (rng.standard_normal((128, d)) * rng.choice([0.05, 1.0, 30.0], (128, 1))).astype(np.float32)
+        out[f"a_{d}"], out[f"b_{d}"] = a, b
+        out[f"l2_{d}"] = oracle.dist_many(oracle.METRIC_L2, a, b, d, impl="ref")
+        out[f"ip_{d}"] = oracle.dist_many(oracle.METRIC_IP, a, b, d, impl="ref")
+    np.savez_compressed(os.path.join(HERE, "distance_kat.npz"), **out)
+
+
+def make_pq_trace():
+    """Scripted NeighborPriorityQueue sequence: fill, exact duplicate, equal distance / different id,
+    eviction from a full pool, insert below the cursor (lo < _cur), pops until empty."""
+    cap = 6
+    ops, ids, dists = [], [], []
+
+    def ins(i, d):
+        ops.append(0), ids.append(i), dists.append(d)
+
+    def pop():
+        ops.append(1), ids.append(0), dists.append(0.0)
+
+    for i, d in [(5, 0.5), (3, 0.3), (9, 0.9), (3, 0.3), (7, 0.5), (4, 0.5)]:
+        ins(i, d)
+    pop(), pop()
+    ins(1, 0.1)  # lo < _cur
+    pop()
+    for i, d in [(8, 0.8), (2, 0.95), (6, 0.2), (10, 0.2), (11, 0.85), (12, 1.5), (9, 0.9)]:
+        ins(i, d)
+    for _ in range(10):
+        pop()
+    ins(13, 0.05)
+    pop(), pop()
+    rng = np.random.default_rng(5)
+    for _ in range(200):  # random tail with ties: distance is a function of the id
+        if rng.random() < 0.3:
+            pop()
+        else:
+            i = int(rng.integers(0, 40))
+            ins(i, float((i * 7) % 11) * 0.25)
+    ops, ids, dists = np.array(ops, np.uint8), np.array(ids, np.uint32), np.array(dists, np.float32)
+    snap = oracle.pq_trace(cap, ops, ids, dists, impl="ref")
+    np.savez_compressed(os.path.join(HERE, "pq_trace.npz"), capacity=cap, ops=ops, ids=ids, dists=dists, snap=snap)
+
+
+if __name__ == "__main__":
+    oracle.build()
+    assert oracle.have_ref(), "oracle/_ref not built"
+    for name in CASES:
+        make_case(name)
+    make_distance_kat()
+    make_pq_trace()
+    print("golden fixtures written to", HERE)

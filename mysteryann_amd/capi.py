@@ -51,6 +51,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RoarError(ERR_DEVICE, "libroargraph_amd.so is not built (run __graft_entry__.build()); "
                                     "there is no fallback implementation")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and the system one has the
+    # same SONAME, so whichever is mapped first serves both.  torch refuses to see the GPU on the
+    # system runtime, therefore let torch map its copy before this library is loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     l = C.CDLL(LIB_PATH)
     vp, u32p, u64p, fp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
     l.roar_last_error.restype = C.c_char_p

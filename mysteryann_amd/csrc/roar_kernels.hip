@@ -302,9 +302,30 @@ __global__ void __launch_bounds__(64, 4) roar_search_kernel(const RoarSearchPara
                     const uint32_t t0 = ww.x & 0xFFFFu, t1 = ww.x >> 16, t2 = ww.y & 0xFFFFu, t3 = ww.y >> 16;
                     const bool hit = (t0 == tag) | (t1 == tag) | (t2 == tag) | (t3 == tag);
                     fresh = isnbr && !hit;
-                    if (fresh) {
-                        const uint32_t way = t0 == 0 ? 0u : t1 == 0 ? 1u : t2 == 0 ? 2u : t3 == 0 ? 3u : (tag & 3u);
-                        vis[4 * set + way] = (uint16_t)tag;
+                    // Insert.  Lanes of this instruction that share a set race for the same empty
+                    // way, so a write into an empty way is verified on the next round and retried
+                    // by the loser; a full set overwrites a victim way without verification (that is
+                    // the only place the table forgets).
+                    bool pending = fresh;
+                    uint32_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
+                    while (__ballot(pending)) {
+                        if (pending) {
+                            const bool present = (a0 == tag) | (a1 == tag) | (a2 == tag) | (a3 == tag);
+                            const bool full = (a0 != 0) & (a1 != 0) & (a2 != 0) & (a3 != 0);
+                            if (present) {
+                                pending = false;
+                            } else {
+                                const uint32_t way = a0 == 0 ? 0u : a1 == 0 ? 1u : a2 == 0 ? 2u : a3 == 0 ? 3u : (tag & 3u);
+                                vis[4 * set + way] = (uint16_t)tag;
+                                if (full) pending = false;
+                            }
+                        }
+                        wave_sync();
+                        if (pending) {
+                            const uint2 w2 = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+                            a0 = w2.x & 0xFFFFu, a1 = w2.x >> 16, a2 = w2.y & 0xFFFFu, a3 = w2.y >> 16;
+                        }
+                        wave_sync();
                     }
                 } else {  // visited_array[nbr] != tag ... = tag  (index_bipartite.cpp:2378,2385)
                     uint32_t tg = 0;

@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS @ recall@10 >= 0.9 on the Text-to-Image-10M shape (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (the batched RoarGraph beam search, one kernel launch) over
+this rank's shard of the 10 000-query OOD batch, inputs already resident in HBM.  Workload
+(config.workload "t2i-10M-ip"): synthetic base 10 M x 200-d f32 + 10 k out-of-distribution queries
+(mysteryann_amd/synth.py), inner-product metric, k = 10, index built in HBM by the
+bootstrap builder and replicated on every GPU.  Multi-GPU: the path shards by query with no
+collective in the data path; every rank searches its OWN 10 000-query OOD batch (per-GPU work
+fixed -> "scaling": "weak"), value = queries all ranks processed / max-over-ranks time.
+
+L_pq is the smallest value of the reference's sweep list (run_roargraph_search_test.sh:13) whose
+recall@10 against exact brute-force ground truth is >= 0.9.
+
+Printed by rank 0: ONE JSON line with the driver's contract fields plus
+  roofline      HBM-gather roofline of the search kernel: algorithmic bytes (reference cmps / hops /
+                scanned counters, SURVEY 8(d) formula) / kernel time measured with HIP events
+  cpu_baseline  the reference's own distance / queue / visited-pool code (oracle/_ref, "reference")
+                or the C restatement ("port") timed on this box's host cores on the same queries
+Diagnostics go to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L_LIST = [10, 15, 20, 25, 30, 35, 40, 45, 50, 55, 60, 65, 70, 75, 80, 85, 90, 95, 100, 110, 120, 130, 140, 150, 160,
+          170, 180, 190, 200, 220, 240, 260, 280, 300, 350, 400, 450, 500, 550, 600, 650, 700, 750, 800, 900, 1000,
+          1100, 1200, 1300, 1400, 1500, 1600, 1700, 1800, 1900, 2000]  # run_roargraph_search_test.sh:13
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048):
+    """Exact top-k by inner product (max dot), ids only.  Test infrastructure (torch matmul)."""
+    nq = queries.shape[0]
+    out = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
+    for q0 in range(0, nq, chunk_q):
+        q = queries[q0:q0 + chunk_q, :d]
+        best_v = torch.full((q.shape[0], k), -float("inf"), device=q.device)
+        best_i = torch.zeros((q.shape[0], k), dtype=torch.int64, device=q.device)
+        for r0 in range(0, base.shape[0], chunk_rows):
+            s = q @ base[r0:r0 + chunk_rows, :d].T
+            v, i = torch.topk(s, k, dim=1)
+            v = torch.cat([best_v, v], 1)
+            i = torch.cat([best_i, i + r0], 1)
+            best_v, sel = torch.topk(v, k, dim=1)
+            best_i = torch.gather(i, 1, sel)
+        out[q0:q0 + chunk_q] = best_i
+    return out
+
+
+def recall_at_k(torch, ids, gt, k):
+    hit = (gt[:, :k, None] == ids[:, None, :k].to(torch.int64)).any(dim=2).sum().item()
+    return hit / float(k * ids.shape[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000, help="base points (10 M = the BASELINE config)")
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--L", type=int, default=0, help="0 = smallest L_pq of the reference sweep with recall >= target")
+    ap.add_argument("--target-recall", type=float, default=0.9)
+    ap.add_argument("--visited", default="lds", choices=["lds", "exact"])
+    ap.add_argument("--build-M", type=int, default=24)
+    ap.add_argument("--build-basecap", type=int, default=32)
+    ap.add_argument("--build-maxdeg", type=int, default=96)
+    ap.add_argument("--build-L", type=int, default=48)
+    ap.add_argument("--build-Msq", type=int, default=48)
+    ap.add_argument("--build-Mpj", type=int, default=24)
+    ap.add_argument("--build-Llearn", type=int, default=128)
+    ap.add_argument("--build-rounds", type=int, default=5)
+    ap.add_argument("--exact-knn", action="store_true", help="exact learn->base kNN lists (torch brute force)")
+    ap.add_argument("--build-phase1-ip", action="store_true", help="phase 1 by the index metric instead of L2")
+    ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sweep", action="store_true", help="print the whole L_pq curve (CSV columns of the reference)")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from mysteryann_amd import index as mi
+    from mysteryann_amd import synth
+
+    t0 = time.time()
+    n_learn = args.learn if args.learn >= 0 else max(args.n // 4, 1000)
+    base, queries, learn = synth.t2i_torch(args.n, args.nq, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
+                                           query_seed=args.seed + 2 + 1000 * rank)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] synthetic T2I-shape data: base {tuple(base.shape)}, queries {tuple(queries.shape)}, "
+        f"learn {n_learn} in {time.time() - t0:.1f}s")
+
+    idx = mi.IndexBipartite(args.dim, args.n, mi.INNER_PRODUCT, None, device=local)
+    idx.SetBaseData(base)
+    learn_knn = None
+    if args.exact_knn and n_learn:
+        t0 = time.time()
+        learn_knn = brute_force_gt(torch, base, args.dim, learn, args.build_Msq).to(torch.int32).contiguous()
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] exact learn->base kNN ({n_learn} x {args.build_Msq}) in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    idx.BuildBootstrapGraph(M=args.build_M, base_cap=args.build_basecap, max_degree=args.build_maxdeg,
+                            L_build=args.build_L, learn=learn if n_learn else None, M_sq=args.build_Msq,
+                            M_pj=args.build_Mpj, L_learn=args.build_Llearn, rounds=args.build_rounds,
+                            phase1_l2=not args.build_phase1_ip, learn_knn=learn_knn)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
+        f"max degree {idx.info('max_degree')}, ep {idx.info('ep')}")
+    del learn
+
+    # this rank's own query batch (independent units, no cross-query dependence: SURVEY 8(e))
+    lo, hi = 0, args.nq
+    myq = queries
+    t0 = time.time()
+    gt = brute_force_gt(torch, base, args.dim, myq, args.k)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] brute-force ground truth for {hi - lo} queries in {time.time() - t0:.1f}s")
+
+    idx.set_option("visited_mode", 1 if args.visited == "lds" else 0)
+
+    def run(L, out=None):
+        return idx.SearchRoarGraphBatchDevice(myq, args.k, L, out=out)
+
+    # choose L_pq
+    curve = []
+    chosen = args.L
+    if chosen == 0 or args.sweep:
+        for L in L_LIST:
+            if L < args.k:
+                continue
+            o = run(L)
+            torch.cuda.synchronize()
+            r = recall_at_k(torch, o["ids"], gt, args.k)
+            if world > 1:
+                t = torch.tensor([r * (hi - lo)], device=dev, dtype=torch.float64)
+                dist.all_reduce(t)
+                r = t.item() / (args.nq * world)
+            ns = idx.info("last_kernel_ns")
+            curve.append((L, (hi - lo) / (ns * 1e-9), float(o["cmps"].float().mean()), ns * 1e-6 / max(hi - lo, 1), r,
+                          float(o["hops"].float().mean())))
+            log(f"[rank {rank}] L_pq={L:5d} recall@{args.k}={r:.4f} kernel={ns / 1e6:.3f} ms "
+                f"cmps={curve[-1][2]:.0f} hops={curve[-1][5]:.1f}")
+            if chosen == 0 and r >= args.target_recall:
+                chosen = L
+                if not args.sweep:
+                    break
+        if chosen == 0:
+            chosen = L_LIST[-1]
+            log(f"[rank {rank}] WARNING: recall target {args.target_recall} not reached, using L_pq={chosen}")
+    if args.sweep and rank == 0:
+        log("L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops")
+        for row in curve:
+            log(",".join(f"{v:.6g}" for v in row))
+
+    out = run(chosen)
+    torch.cuda.synchronize()
+    rec = recall_at_k(torch, out["ids"], gt, args.k)
+
+    # reference-algorithm counters for the roofline's algorithmic bytes: EXACT visited mode, untimed
+    idx.set_option("visited_mode", 0)
+    ex = run(chosen)
+    torch.cuda.synchronize()
+    idx.set_option("visited_mode", 1 if args.visited == "lds" else 0)
+    dpad = idx.info("dim_padded")
+    alg_bytes = (4 * dpad * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum() + 8 * ex["hops"].double().sum()
+                 + (4 * dpad + 8 * args.k) * (hi - lo)).item()
+    same_ids = bool((ex["ids"] == out["ids"]).all().item())
+
+    # timed region
+    for _ in range(args.warmup):
+        run(chosen, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        run(chosen, out)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)  # same stream as the launches (torch's current stream is passed down)
+    last_kernel_ms = idx.info("last_kernel_ns") * 1e-6
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = t.item()
+        t = torch.tensor([rec * (hi - lo)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        rec = t.item() / (args.nq * world)
+    ms_per_step = wall * 1e3 / args.steps
+    qps = args.nq * world * args.steps / wall
+    kernel_ms = gpu_ms / args.steps
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "t2i-10M-ip" if args.n == 10_000_000 else f"t2i-shape-n{args.n}", "n_base": args.n,
+                   "dim": args.dim, "metric": "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
+                   "recall_at_10": rec, "parallelism": f"query batches sharded over {world} GPU(s), index replicated, no collective",
+                   "visited": args.visited, "index": f"bootstrap M={args.build_M} cap={args.build_basecap}/{args.build_maxdeg} "
+                                                      f"L={args.build_L}; projection learn={n_learn} Msq={args.build_Msq} "
+                                                      f"Mpj={args.build_Mpj} L={args.build_Llearn} x{args.build_rounds}",
+                   "avg_degree": idx.info("nedges") / args.n, "build_seconds": build_s},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "roar_search_kernel", "kernel_ms": kernel_ms, "last_launch_ms": last_kernel_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes, "queries_per_launch": hi - lo,
+                     "avg_cmps": float(ex["cmps"].float().mean()), "avg_hops": float(ex["hops"].float().mean()),
+                     "avg_scanned": float(ex["scanned"].float().mean()),
+                     "lds_mode_cmps": float(out["cmps"].float().mean()), "grid": idx.info("last_grid"),
+                     "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids},
+    }
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(np, torch, idx, base, myq, out, args, chosen)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, torch, idx, base, myq, out, args, L):
+    """The reference's loop shape (100 warm-up queries, then omp parallel for schedule(dynamic,1),
+    tests/test_search_roargraph.cpp:198-212) on the host cores, same graph, same queries."""
+    import oracle
+
+    impl = "ref" if oracle.have_ref() else "port"
+    t0 = time.time()
+    hb = base.cpu().numpy()
+    ep, off, nbrs = idx.GetProjectionGraph()
+    hq = myq.cpu().numpy()
+    if hq.shape[1] != hb.shape[1]:
+        hq = np.ascontiguousarray(np.pad(hq, ((0, 0), (0, hb.shape[1] - hq.shape[1]))))
+    log(f"[cpu] host copies of base + graph in {time.time() - t0:.1f}s; impl={impl}")
+    threads = oracle.max_threads(impl)
+    dpad = idx.info("dim_padded")
+    oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, 1, threads=1, impl=impl, dim=dpad)  # warm-up
+    done, spent, reps, res = 0, 0.0, 0, None
+    while spent < args.cpu_seconds and reps < 50:
+        t0 = time.perf_counter()
+        res = oracle.search_batch(hb, off, nbrs, ep, hq, args.k, L, 1, threads=threads, impl=impl, dim=dpad)
+        spent += time.perf_counter() - t0
+        done += hq.shape[0]
+        reps += 1
+    gpu_ids = out["ids"].cpu().numpy().view(np.uint32)
+    gpu_d = out["dists"].cpu().numpy()
+    ids_equal = float((gpu_ids == res["ids"]).all(axis=1).mean())
+    return {"value": done / spent, "unit": "queries/s", "cores": threads,
+            "kind": "reference" if impl == "ref" else "port",
+            "sample": f"all {hq.shape[0]} queries x {reps} passes at L_pq={L}, omp dynamic,1 over {threads} threads "
+                      f"({'reference distance/queue/visited headers compiled in place, search loop restated' if impl == 'ref' else 'C restatement'})",
+            "gpu_vs_cpu_ids_identical_fraction": ids_equal,
+            "gpu_vs_cpu_max_abs_dist_diff": float(np.abs(gpu_d - res["dists"]).max())}
+
+
+if __name__ == "__main__":
+    main()

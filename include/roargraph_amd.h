@@ -73,6 +73,41 @@ int roar_save_graph_file(roar_index *idx, const char *path);
 int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *nedges, uint64_t *offsets,
                        uint32_t *nbrs);
 
+/* ---- bootstrap builder (scaffolding for measurement, NOT the reference's builder) ----------------
+ * No index can be downloaded to the GPU box, so one is built in HBM from the loaded base rows, with
+ * the search kernel as the work-horse:
+ *   phase 1  incremental batch insertion: each node is searched in the graph built so far (L_build),
+ *            gets its M nearest as out-edges and is appended to their rows while they hold fewer than
+ *            base_cap entries; entry point = node nearest the centroid (CalculateProjectionep,
+ *            src/index_bipartite.cpp:2004-2041).
+ *   phase 2  projection of n_learn training queries (resident in HBM, drawn from the QUERY
+ *            distribution), `rounds` times: search (L_learn) -> M_sq nearest base points; pivot = the
+ *            nearest; the others are occlusion-pruned against the pivot to at most M_pj and linked
+ *            pivot <-> kept.  This follows the shape of BuildRoarGraph / LinkProjection /
+ *            PruneBiSearchBaseGetBase (src/index_bipartite.cpp:143-233, 1043-1093, 1612-1694) but uses
+ *            approximate neighbour lists from the graph itself instead of an exact learn->base kNN file.
+ * Rows never exceed max_degree.  The result is an ordinary projection graph: roar_save_graph_file
+ * writes the reference's index format.  The reference's own builder stays SURVEY 8(f) "next" #1. */
+typedef struct roar_build_params {
+    uint32_t M;          /* out-edges of a new node in phase 1 (<= 64) */
+    uint32_t base_cap;   /* row capacity during phase 1 */
+    uint32_t max_degree; /* final row capacity */
+    uint32_t L_build;    /* pool length of the phase-1 searches */
+    uint64_t max_batch;  /* nodes / queries per launch (0 = 2^19) */
+    const float *learn_dev; /* training queries in HBM, may be NULL */
+    uint64_t n_learn;
+    uint32_t learn_stride_floats;
+    uint32_t M_sq;       /* neighbours taken per training query (<= 64); run_roargraph_test.sh:9 uses 100 */
+    uint32_t M_pj;       /* kept per pivot after pruning; the reference's M_pjbp (35) */
+    uint32_t L_learn;    /* pool length of the phase-2 searches */
+    uint32_t rounds;     /* passes over the training queries */
+    uint32_t phase1_l2;  /* 1: phase 1 links base points by L2 whatever the index metric is */
+    const uint32_t *learn_knn_dev; /* optional exact learn->base kNN ids in HBM, [n_learn][M_sq], nearest first:
+                                      the input of the reference builder (LoadLearnBaseKNN,
+                                      src/index_bipartite.cpp:2622-2639); projected before the search rounds */
+} roar_build_params;
+int roar_build_graph(roar_index *idx, const roar_build_params *params);
+
 /* ---- search ---------------------------------------------------------------------------------
  * IndexBipartite::SearchRoarGraph  src/index_bipartite.cpp:2311-2420, batched over nq queries
  * (the reference's `#pragma omp parallel for` over queries, tests/test_search_roargraph.cpp:203-209,

@@ -19,9 +19,17 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_SHORT = 0, -1, -2, -3, -4, -5
 SYMBOLS = [
     "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
     "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
-    "roar_get_graph_csr", "roar_search_batch", "roar_search_batch_device", "roar_distances",
+    "roar_get_graph_csr", "roar_build_graph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
 ]
+
+
+class BuildParams(C.Structure):
+    """struct roar_build_params (include/roargraph_amd.h)"""
+    _fields_ = [("M", C.c_uint32), ("base_cap", C.c_uint32), ("max_degree", C.c_uint32), ("L_build", C.c_uint32),
+                ("max_batch", C.c_uint64), ("learn_dev", C.c_void_p), ("n_learn", C.c_uint64),
+                ("learn_stride_floats", C.c_uint32), ("M_sq", C.c_uint32), ("M_pj", C.c_uint32),
+                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("learn_knn_dev", C.c_void_p)]
 
 
 class RoarError(RuntimeError):
@@ -32,7 +40,7 @@ class RoarError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_capi.cpp", "roar_device.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_capi.cpp", "roar_device.h")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -71,6 +79,7 @@ def lib():
     l.roar_set_graph_csr.argtypes = [vp, C.c_uint32, C.c_uint64, u64p, u32p]
     l.roar_save_graph_file.argtypes = [vp, C.c_char_p]
     l.roar_get_graph_csr.argtypes = [vp, u32p, u64p, u64p, u64p, u32p]
+    l.roar_build_graph.argtypes = [vp, C.POINTER(BuildParams)]
     l.roar_search_batch.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, u32p, u32p]
     l.roar_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                            vp, vp]

@@ -1,0 +1,391 @@
+// roar_build.hip -- in-HBM bootstrap graph builder (gfx950).
+//
+// Why it exists: no dataset or index can be downloaded to the GPU box, so every measurement at
+// 1 M - 100 M points needs an index built there, in minutes, from synthetic vectors.  This is NOT
+// the reference's LinkProjection (src/index_bipartite.cpp:1043-1277, SURVEY 8(f) "next" #1); it is an
+// incremental batch insertion that reuses the search kernel as its work-horse and emits the
+// same fixed-stride adjacency the search reads, from which the reference's index file
+// (u32 ep; u32 npts; npts x {u32 deg; u32 nbr[deg]}) is written unchanged.
+//
+//   entry point   node nearest the centroid, as CalculateProjectionep (index_bipartite.cpp:2004-2041)
+//   seeds         the first `seed` nodes (+ the entry point) start with pseudo-random links
+//   batches       nodes [a, b): search the graph built so far with the node's own vector
+//                 (L_build), keep the M nearest as out-edges, append the node to each of them
+//                 (reverse edge) while that row has room (max_degree)
+//   projection    optional: training queries (drawn from the QUERY distribution) are searched and
+//                 the nearest result (the pivot) is linked to the other results, which is the idea
+//                 of the projected bipartite graph in its simplest form
+//   rescue        nodes nobody points to are forced into a row of one of their own neighbours
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t f2ord_b(float f) {
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// column sums of the base matrix: sums[d] += sum over a slab of rows (atomics, one per column per block)
+__global__ void colsum_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, u64 rows_per_block,
+                              float *sums) {
+    const u64 r0 = (u64)blockIdx.x * rows_per_block;
+    const u64 r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) {
+        float s = 0.f;
+        for (u64 r = r0; r < r1; ++r) s += base[r * ld + c];
+        atomicAdd(&sums[c], s);
+    }
+}
+
+// squared L2 distance of every row to centre (= sums / n); global argmin through a u64 atomicMin
+__global__ void nearest_to_centre_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n,
+                                         const float *__restrict__ sums, u64 *best) {
+    const int lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const float inv = 1.0f / (float)n;
+    u64 local = ~0ull;
+    for (u64 r = wave; r < n; r += nwaves) {
+        float s = 0.f;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            const float d = sums[c] * inv - base[r * ld + c];
+            s += d * d;
+        }
+        s = wave_sum(s);
+        const u64 key = ((u64)f2ord_b(s) << 32) | (uint32_t)r;
+        local = key < local ? key : local;
+    }
+    if (lane == 0 && local != ~0ull) atomicMin(best, local);
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// seed rows: M pseudo-random links among the seed set {0..seed-1} (+ ep mapped to index `seed`)
+__global__ void seed_rows_kernel(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t M) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = seed + (ep >= seed ? 1u : 0u);
+    if (i >= total) return;
+    const uint32_t v = i < seed ? i : ep;
+    uint32_t *row = adj + (u64)v * S;
+    uint32_t deg = 0;
+    for (uint32_t j = 0; j < M && j + 1 < total; ++j) {
+        uint32_t t = mix32(i * 0x9E3779B9u + j * 0x85EBCA6Bu + 12345u) % total;
+        if (t == i) t = (t + 1) % total;
+        const uint32_t u = t < seed ? t : ep;
+        bool dup = false;
+        for (uint32_t q = 0; q < deg; ++q) dup |= row[1 + q] == u;
+        if (!dup) row[1 + deg++] = u;
+    }
+    row[0] = deg;
+}
+
+// link nodes a..a+count-1 (thread per node): out-edges = its M search results, reverse edges appended.
+// relink != 0: the node already has a row (seed): overwrite its first slots, keep what was appended.
+__global__ void link_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count,
+                            const uint32_t *__restrict__ res, uint32_t M, uint32_t ep, uint32_t *indeg, int relink) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t v = a + i;
+    if (!relink && v == ep) return;  // the entry point was linked with the seeds
+    uint32_t *row = adj + (u64)v * S;
+    uint32_t deg = 0;
+    for (uint32_t j = 0; j < M; ++j) {
+        const uint32_t u = res[(u64)i * M + j];
+        if (u == 0xFFFFFFFFu || u == v) continue;
+        row[1 + deg++] = u;
+        atomicAdd(&indeg[u], 1u);
+        // reverse edge u -> v while row u has room
+        uint32_t *urow = adj + (u64)u * S;
+        const uint32_t old = atomicAdd(&urow[0], 1u);
+        if (old < max_deg) {
+            urow[1 + old] = v;
+            atomicAdd(&indeg[v], 1u);
+        } else {
+            atomicSub(&urow[0], 1u);
+        }
+    }
+    if (relink) {
+        if (row[0] < deg) row[0] = deg;
+    } else {
+        // reverse edges may already have been appended to this row by batch mates? No: v is not in the
+        // graph while its batch is searched, nobody can have v as a result.
+        row[0] = deg;
+    }
+}
+
+// projection step, one wave per training query.  res[t] = the query's (approximate) nearest base
+// points, nearest first.  pivot = res[0]; the other C-1 results are the candidates.  Following the
+// shape of the reference's projection (LinkProjection, src/index_bipartite.cpp:1059-1093, and the
+// occlusion rule of PruneBiSearchBaseGetBase, :1612-1694): candidates are ordered by their base-to-
+// base distance to the pivot, one is kept unless an already kept one is closer to it than the
+// pivot is, the list is back-filled with the nearest leftovers up to Mp, pivot -> kept edges are
+// written and each kept node gets the reverse edge.
+// Rows hold [bootstrap edges | projection edges]; base_deg[v] is where the projection part starts.
+template <bool IP>
+__global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg,
+                                                          const uint32_t *__restrict__ base_deg,
+                                                          const float *__restrict__ base, u64 ld, uint32_t dim,
+                                                          uint32_t count, const uint32_t *__restrict__ res,
+                                                          uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg,
+                                                          uint32_t salt) {
+    extern __shared__ __align__(16) float rows[];  // C x (dim + 1) floats, row 0 = pivot
+    const int lane = threadIdx.x;
+    const uint32_t rs = dim + 1;
+    for (uint32_t t = blockIdx.x; t < count; t += gridDim.x) {
+        const uint32_t *r = res + (u64)t * M;
+        uint32_t myid = (uint32_t)lane < C ? r[lane] : 0xFFFFFFFFu;
+        const uint32_t pivot = __builtin_amdgcn_readfirstlane((int)myid);
+        if (pivot == 0xFFFFFFFFu) continue;
+        if (lane > 0 && myid == pivot) myid = 0xFFFFFFFFu;
+        // gather the rows (coalesced: the wave walks one row at a time)
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)c);
+            if (id == 0xFFFFFFFFu) continue;
+            const float *src = base + (u64)id * ld;
+            for (uint32_t i = lane; i < dim; i += 64) rows[c * rs + i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // distance of every candidate to the pivot (lane j owns candidate j)
+        auto dist_rows = [&](uint32_t a, uint32_t b) -> float {
+            float s = 0.f;
+            const float *x = rows + a * rs, *y = rows + b * rs;
+            for (uint32_t i = 0; i < dim; ++i) {
+                if (IP) s = __builtin_fmaf(x[i], y[i], s);
+                else { const float d = x[i] - y[i]; s = __builtin_fmaf(d, d, s); }
+            }
+            return IP ? -s : s;
+        };
+        const bool cand = lane > 0 && (uint32_t)lane < C && myid != 0xFFFFFFFFu;
+        float dp = cand ? dist_rows((uint32_t)lane, 0) : __builtin_inff();
+        const u64 key = cand ? (((u64)f2ord_b(dp) << 32) | myid) : ~0ull;
+        // order candidates by (distance to pivot, id); duplicates of an earlier lane drop out
+        uint32_t rank = 0;
+        bool dupl = false;
+        for (uint32_t j = 1; j < C; ++j) {
+            const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)j);
+            const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)j);
+            const u64 kj = ((u64)khi << 32) | klo;
+            if (kj == ~0ull || (int)j == lane) continue;
+            if (kj < key) rank++;
+            else if (kj == key && (int)j < lane) dupl = true;
+        }
+        const bool live = cand && !dupl;
+        // greedy occlusion in sorted order; `kept` lanes hold kept candidates
+        bool kept = false;
+        uint32_t nkept = 0;
+        // note: ranks of live lanes are a permutation of 0..nlive-1 only if dropped duplicates are
+        // not counted; a duplicate has an equal key so it never increments anyone's rank.
+        for (uint32_t o = 0; o < C && nkept < Mp; ++o) {
+            const u64 who = __ballot(live && rank == o);
+            if (!who) continue;
+            const int c = __ffsll((long long)who) - 1;
+            const float dc = __shfl(dp, c);
+            bool occl = false;
+            if (kept) occl = dist_rows((uint32_t)lane, (uint32_t)c) < dc;
+            if (__ballot(occl) == 0) {
+                if (lane == c) kept = true;
+                nkept++;
+            }
+        }
+        // back-fill with the nearest leftovers (:1685-1691)
+        for (uint32_t o = 0; o < C && nkept < Mp; ++o) {
+            const u64 who = __ballot(live && !kept && rank == o);
+            if (!who) continue;
+            if (lane == __ffsll((long long)who) - 1) kept = true;
+            nkept++;
+        }
+        // write pivot -> kept (projection part of the row), and kept -> pivot
+        if (kept) {
+            uint32_t *prow = adj + (u64)pivot * S;
+            const uint32_t pd = prow[0] < max_deg ? prow[0] : max_deg;
+            bool have = false;
+            for (uint32_t q = 0; q < pd; ++q) have |= prow[1 + q] == myid;
+            if (!have) {
+                const uint32_t old = atomicAdd(&prow[0], 1u);
+                if (old < max_deg) {
+                    prow[1 + old] = myid;
+                    atomicAdd(&indeg[myid], 1u);
+                } else {
+                    atomicSub(&prow[0], 1u);
+                    const uint32_t b0 = base_deg[pivot] < max_deg ? base_deg[pivot] : max_deg;
+                    if (b0 < max_deg) {  // row full: refresh a projection slot
+                        const uint32_t slot = b0 + mix32(myid ^ salt ^ (t * 0x9E3779B9u)) % (max_deg - b0);
+                        prow[1 + slot] = myid;
+                    }
+                }
+            }
+            uint32_t *urow = adj + (u64)myid * S;
+            const uint32_t ud = urow[0] < max_deg ? urow[0] : max_deg;
+            have = false;
+            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == pivot;
+            if (!have) {
+                const uint32_t old = atomicAdd(&urow[0], 1u);
+                if (old < max_deg) {
+                    urow[1 + old] = pivot;
+                    atomicAdd(&indeg[pivot], 1u);
+                } else {
+                    atomicSub(&urow[0], 1u);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+__global__ void snapshot_degree_kernel(const uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n, uint32_t *base_deg) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t d = adj[v * S];
+    base_deg[v] = d < max_deg ? d : max_deg;
+}
+
+__global__ void clamp_degree_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    if (adj[v * S] > max_deg) adj[v * S] = max_deg;
+}
+
+// nodes without an in-edge: push v into the row of its r-th own neighbour (append, else last slot)
+__global__ void rescue_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n, uint32_t ep, uint32_t r,
+                              uint32_t *indeg, uint32_t *orphans) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || v == ep || indeg[v] != 0) return;
+    atomicAdd(orphans, 1u);
+    const uint32_t *row = adj + v * S;
+    const uint32_t deg = row[0];
+    if (deg == 0) return;
+    const uint32_t u = row[1 + (r % deg)];
+    uint32_t *urow = adj + (u64)u * S;
+    const uint32_t old = atomicAdd(&urow[0], 1u);
+    if (old < max_deg) {
+        urow[1 + old] = (uint32_t)v;
+    } else {
+        atomicSub(&urow[0], 1u);
+        const uint32_t victim = urow[max_deg];
+        urow[max_deg] = (uint32_t)v;  // replaces the last slot
+        if (victim != (uint32_t)v) atomicSub(&indeg[victim], 1u);
+    }
+    atomicAdd(&indeg[v], 1u);
+}
+
+__global__ void degree_stats_kernel(const uint32_t *adj, uint32_t S, u64 n, u64 *sum, uint32_t *maxd) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = v < n ? adj[v * S] : 0u;
+    uint32_t m = d;
+    u64 s = d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        const uint32_t t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sum, s);
+        atomicMax(maxd, m);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
+                         void *stream) {
+    hipError_t e = hipMemsetAsync(sum_dev, 0, 8, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(max_dev, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(degree_stats_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
+                       (u64)n, (u64 *)sum_dev, max_dev);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_entry_point(const float *base, uint64_t ld, uint32_t dim, uint64_t n, float *sums_dev /*dim*/,
+                        unsigned long long *best_dev, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums_dev, 0, dim * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(best_dev, 0xFF, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t rows_per_block = 4096;
+    const uint32_t grid = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, st, base, (u64)ld, dim, (u64)n, (u64)rows_per_block,
+                       sums_dev);
+    hipLaunchKernelGGL(nearest_to_centre_kernel, dim3(2048), dim3(256), 0, st, base, (u64)ld, dim, (u64)n, sums_dev,
+                       (u64 *)best_dev);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_seed(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t M, void *stream) {
+    const uint32_t total = seed + 1;
+    hipLaunchKernelGGL(seed_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, adj, S, seed, ep,
+                       M);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+                 uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(link_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, adj, S, max_deg, a,
+                       count, res, M, ep, indeg, relink);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, const float *base,
+                    uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C,
+                    uint32_t Mp, uint32_t *indeg, uint32_t salt, void *stream) {
+    if (count == 0) return 0;
+    const uint32_t lds = C * (dim + 1) * sizeof(float);
+    const uint32_t grid = count < 8192u ? count : 8192u;
+    if (metric_ip) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)project_prune_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(project_prune_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, max_deg,
+                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)project_prune_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(project_prune_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, max_deg,
+                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt);
+    }
+    return (int)hipGetLastError();
+}
+
+int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
+                            void *stream) {
+    hipLaunchKernelGGL(snapshot_degree_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj,
+                       S, max_deg, (u64)n, base_deg);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream) {
+    hipLaunchKernelGGL(clamp_degree_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
+                       max_deg, (u64)n);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
+                   uint32_t *orphans, void *stream) {
+    hipError_t e = hipMemsetAsync(orphans, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rescue_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
+                       max_deg, (u64)n, ep, r, indeg, orphans);
+    return (int)hipGetLastError();
+}
+}

@@ -14,6 +14,24 @@
 #include "../../include/roargraph_amd.h"
 #include "roar_device.h"
 
+extern "C" {  // roar_build.hip
+int roar_bk_entry_point(const float *base, uint64_t ld, uint32_t dim, uint64_t n, float *sums_dev,
+                        unsigned long long *best_dev, void *stream);
+int roar_bk_seed(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t M, void *stream);
+int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+                 uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream);
+int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, const float *base,
+                    uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C,
+                    uint32_t Mp, uint32_t *indeg, uint32_t salt, void *stream);
+int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
+                            void *stream);
+int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
+int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
+                   uint32_t *orphans, void *stream);
+int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
+                         void *stream);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -141,6 +159,29 @@ int ensure_tags(roar_index *idx, uint32_t slots) {
     HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->epochs, 0, (size_t)slots * sizeof(uint32_t)));
     idx->slots = slots;
+    return ROAR_OK;
+}
+
+// Host CSR copy of a graph that was built on the device (download + strip the row padding).
+int ensure_host_csr(roar_index *idx) {
+    if (!idx->h_off.empty() || idx->gn == 0) return ROAR_OK;
+    const uint64_t n = idx->gn;
+    const uint32_t S = idx->adj_stride;
+    idx->h_off.assign(n + 1, 0);
+    idx->h_nbrs.clear();
+    const uint64_t chunk = std::max<uint64_t>(1, (128ull << 20) / (S * 4));
+    std::vector<uint32_t> buf((size_t)chunk * S);
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint64_t cnt = std::min(chunk, n - r0);
+        HIP_TRY(hipMemcpy(buf.data(), idx->adj + r0 * S, (size_t)cnt * S * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < cnt; ++i) {
+            const uint32_t *row = buf.data() + i * S;
+            idx->h_off[r0 + i] = idx->h_nbrs.size();
+            idx->h_nbrs.insert(idx->h_nbrs.end(), row + 1, row + 1 + row[0]);
+        }
+    }
+    idx->h_off[n] = idx->h_nbrs.size();
+    idx->nedges = idx->h_nbrs.size();
     return ROAR_OK;
 }
 
@@ -452,6 +493,11 @@ int roar_load_graph_file(roar_index *idx, const char *path) {
 int roar_save_graph_file(roar_index *idx, const char *path) {
     if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
     if (idx->gn == 0) return fail(ROAR_ERR_ARG, "no graph loaded");
+    {
+        int e = use_device(idx);
+        if (!e) e = ensure_host_csr(idx);
+        if (e) return e;
+    }
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ROAR_ERR_IO, "cannot open file");  // src/index_bipartite.cpp:2608-2610
     uint32_t hdr[2] = {idx->ep, (uint32_t)idx->gn};
@@ -468,11 +514,135 @@ int roar_save_graph_file(roar_index *idx, const char *path) {
 int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *nedges, uint64_t *offsets,
                        uint32_t *nbrs) {
     if (!idx) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (idx->gn) {
+        int e = use_device(idx);
+        if (!e) e = ensure_host_csr(idx);
+        if (e) return e;
+    }
     if (ep) *ep = idx->ep;
     if (n) *n = idx->gn;
     if (nedges) *nedges = idx->nedges;
     if (offsets && idx->gn) memcpy(offsets, idx->h_off.data(), (idx->gn + 1) * sizeof(uint64_t));
     if (nbrs && idx->nedges) memcpy(nbrs, idx->h_nbrs.data(), idx->nedges * sizeof(uint32_t));
+    return ROAR_OK;
+}
+
+int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
+    if (!idx || !bp) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "build needs base vectors in HBM");
+    const uint32_t M = bp->M, base_cap = bp->base_cap, max_degree = bp->max_degree, L_build = bp->L_build;
+    const uint32_t C = bp->M_sq, Mp = bp->M_pj, L_learn = bp->L_learn, rounds = bp->rounds;
+    const uint64_t n_learn = bp->learn_dev ? bp->n_learn : 0;
+    if (M == 0 || M > 64 || base_cap < M || max_degree < base_cap || max_degree > 1023 || L_build < M)
+        return fail(ROAR_ERR_ARG, "need 1 <= M <= 64, M <= base_cap <= max_degree <= 1023, L_build >= M");
+    if (idx->n >= (1ull << 31)) return fail(ROAR_ERR_ARG, "more than 2^31 base points are not supported");
+    if (n_learn && (bp->learn_stride_floats < idx->dim_pad || (bp->learn_stride_floats & 3) || C < 2 || C > 64 ||
+                    Mp == 0 || L_learn < C))
+        return fail(ROAR_ERR_ARG, "bad training-query arguments (need 2 <= M_sq <= 64 <= ..., L_learn >= M_sq)");
+    int e = use_device(idx);
+    if (e) return e;
+    free_graph(idx);
+    const uint64_t n = idx->n;
+    const uint32_t S = round_up(max_degree + 1, 32);
+    HIP_TRY(hipMalloc((void **)&idx->adj, ((size_t)n * S + 64) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->adj, 0, ((size_t)n * S + 64) * sizeof(uint32_t)));
+    idx->adj_stride = S;
+    idx->gn = n;
+    idx->max_deg = max_degree;
+    uint64_t max_batch = bp->max_batch ? bp->max_batch : (1u << 19);
+    max_batch = std::min<uint64_t>(max_batch, std::max<uint64_t>(n, n_learn));
+    const uint64_t cap = std::max<uint64_t>(max_batch, 1025);
+    const uint32_t K = std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u);  // result row width
+    if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
+    uint32_t *res_ids = nullptr, *indeg = nullptr, *scratch = nullptr, *base_deg = nullptr;
+    float *res_d = nullptr, *sums = nullptr;
+    HIP_TRY(hipMalloc((void **)&res_ids, (size_t)cap * K * 4));
+    HIP_TRY(hipMalloc((void **)&res_d, (size_t)cap * K * 4));
+    HIP_TRY(hipMalloc((void **)&indeg, (size_t)n * 4));
+    HIP_TRY(hipMemset(indeg, 0, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&base_deg, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&scratch, 16));
+    const int saved_mode = idx->visited_mode;
+    auto cleanup = [&]() {
+        (void)hipFree(res_ids); (void)hipFree(res_d); (void)hipFree(indeg); (void)hipFree(sums); (void)hipFree(scratch);
+        (void)hipFree(base_deg);
+        idx->visited_mode = saved_mode;
+        idx->ip = idx->metric != ROAR_METRIC_L2;
+    };
+#define BK_TRY(call)                                                                        \
+    do {                                                                                    \
+        int rc_ = (call);                                                                   \
+        if (rc_ != 0) {                                                                     \
+            cleanup();                                                                      \
+            return fail(ROAR_ERR_DEVICE, "%s: %s", #call, hipGetErrorString((hipError_t)rc_)); \
+        }                                                                                   \
+    } while (0)
+    // entry point: node nearest the centroid (CalculateProjectionep, src/index_bipartite.cpp:2004-2041)
+    BK_TRY(roar_bk_entry_point(idx->base, idx->ld, idx->dim_pad, n, sums, (unsigned long long *)scratch, nullptr));
+    unsigned long long best = 0;
+    HIP_TRY(hipMemcpy(&best, scratch, 8, hipMemcpyDeviceToHost));
+    idx->ep = (uint32_t)(best & 0xFFFFFFFFu);
+    const uint32_t seed = (uint32_t)std::min<uint64_t>(n, 1024);
+    BK_TRY(roar_bk_seed(idx->adj, S, seed, idx->ep, std::min<uint32_t>(M, seed - 1), nullptr));
+    idx->visited_mode = ROAR_VISITED_LDS;
+    const bool saved_ip = idx->ip;
+    auto search = [&](const float *q, uint64_t cnt, uint32_t qs, uint32_t k, uint32_t L) -> int {
+        return roar_search_batch_device(idx, q, cnt, qs, k, L, res_ids, res_d, nullptr, nullptr, nullptr, nullptr, nullptr);
+    };
+    // phase 1 may link base points by L2 even when the index metric is IP: base-to-base inner
+    // products send every node to the few large-norm points and leave the rest without in-edges.
+    if (bp->phase1_l2) idx->ip = false;
+    // phase 1: base-to-base links, rows capped at base_cap
+    for (uint64_t a = seed; a < n;) {
+        const uint64_t cnt = std::min<uint64_t>(std::min<uint64_t>(max_batch, a), n - a);
+        if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, M, L_build))) { cleanup(); return e; }
+        BK_TRY(roar_bk_link(idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
+        a += cnt;
+    }
+    // seeds started with random links: give them real neighbours now that the graph exists
+    if ((e = search(idx->base, seed, idx->ld, M, L_build))) { cleanup(); return e; }
+    BK_TRY(roar_bk_link(idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
+    idx->ip = saved_ip;
+    BK_TRY(roar_bk_clamp(idx->adj, S, base_cap, n, nullptr));
+    BK_TRY(roar_bk_snapshot_degree(idx->adj, S, max_degree, n, base_deg, nullptr));
+    // phase 2: projection of the training queries, `rounds` times over the improving graph
+    // exact learn -> base kNN lists (the reference builder's input, LoadLearnBaseKNN,
+    // src/index_bipartite.cpp:2622-2639) are projected first when the caller has them
+    if (bp->learn_knn_dev && bp->n_learn) {
+        for (uint64_t a = 0; a < bp->n_learn; a += max_batch) {
+            const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_learn - a);
+            BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
+                                   (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u, nullptr));
+            BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+        }
+    }
+    for (uint32_t r = 0; r < rounds && n_learn; ++r) {
+        for (uint64_t a = 0; a < n_learn; a += max_batch) {
+            const uint64_t cnt = std::min<uint64_t>(max_batch, n_learn - a);
+            if ((e = search(bp->learn_dev + a * bp->learn_stride_floats, cnt, bp->learn_stride_floats, C, L_learn))) {
+                cleanup();
+                return e;
+            }
+            BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
+                                   (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), nullptr));
+            BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+        }
+    }
+    BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+    for (uint32_t r = 0; r < 8; ++r) {
+        BK_TRY(roar_bk_rescue(idx->adj, S, max_degree, n, idx->ep, r, indeg, scratch, nullptr));
+        uint32_t orphans = 0;
+        HIP_TRY(hipMemcpy(&orphans, scratch, 4, hipMemcpyDeviceToHost));
+        if (orphans == 0) break;
+    }
+    BK_TRY(roar_bk_degree_stats(idx->adj, S, n, (unsigned long long *)scratch, scratch + 2, nullptr));
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));
+    idx->nedges = st[0];
+    idx->max_deg = (uint32_t)(st[1] & 0xFFFFFFFFu);
+#undef BK_TRY
+    cleanup();
     return ROAR_OK;
 }
 

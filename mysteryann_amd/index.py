@@ -101,6 +101,22 @@ class IndexBipartite:
         capi.check(self._lib.roar_get_graph_csr(self._h, None, None, None, capi.u64p(offsets), capi.u32p(nbrs)))
         return ep.value, offsets, nbrs[:ne.value]
 
+    def BuildBootstrapGraph(self, M=24, base_cap=32, max_degree=64, L_build=48, max_batch=0, learn=None, M_sq=32,
+                            M_pj=16, L_learn=64, rounds=2, phase1_l2=True, learn_knn=None):
+        """In-HBM bootstrap builder (roar_build_graph): NOT the reference's BuildRoarGraph; it exists so
+        that full-size synthetic indexes can be made on the GPU box.  `learn`: optional CUDA/HIP torch
+        tensor of training queries [n_learn, stride >= dim_padded]."""
+        bp = capi.BuildParams(M=M, base_cap=base_cap, max_degree=max_degree, L_build=L_build, max_batch=max_batch,
+                              learn_dev=None, n_learn=0, learn_stride_floats=0, M_sq=M_sq, M_pj=M_pj,
+                              L_learn=L_learn, rounds=rounds, phase1_l2=1 if phase1_l2 else 0)
+        if learn is not None:
+            assert learn.is_cuda and learn.is_contiguous()
+            bp.learn_dev, bp.n_learn, bp.learn_stride_floats = learn.data_ptr(), learn.shape[0], learn.shape[1]
+        if learn_knn is not None:  # int32/uint32 CUDA tensor [n_learn, M_sq]
+            assert learn_knn.is_cuda and learn_knn.is_contiguous() and learn_knn.shape[1] == M_sq
+            bp.learn_knn_dev, bp.n_learn = learn_knn.data_ptr(), learn_knn.shape[0]
+        capi.check(self._lib.roar_build_graph(self._h, C.byref(bp)))
+
     def InitVisitedListPool(self, num_threads):
         """index_bipartite.h:133"""
         capi.check(self._lib.roar_init_visited_pool(self._h, int(num_threads)))

@@ -65,7 +65,7 @@ def webvid_numpy(n, nq, d=512, seed=1234, n_learn=0):
     return unit(base), unit(q), (unit(learn) if learn is not None else None)
 
 
-def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, row_stride=None):
+def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, row_stride=None, query_seed=None):
     """Full-size T2I-shape set generated in HBM.  Returns (base [n, row_stride], queries [nq, d], learn|None)."""
     import torch
 
@@ -92,6 +92,6 @@ def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, 
             out[i:i + mm] = z @ B + (0.1 * float(s)) * e
         return out
 
-    q = queries(nq, seed + 2)
+    q = queries(nq, seed + 2 if query_seed is None else query_seed)
     learn = queries(n_learn, seed + 3) if n_learn else None
     return base, q, learn

@@ -76,14 +76,18 @@ def main():
     ap.add_argument("--L", type=int, default=0, help="0 = smallest L_pq of the reference sweep with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.9)
     ap.add_argument("--visited", default="lds", choices=["lds", "exact"])
-    ap.add_argument("--build-M", type=int, default=24)
-    ap.add_argument("--build-basecap", type=int, default=32)
-    ap.add_argument("--build-maxdeg", type=int, default=96)
+    ap.add_argument("--build-M", type=int, default=16)
+    ap.add_argument("--build-basecap", type=int, default=64)
+    ap.add_argument("--build-maxdeg", type=int, default=128)
     ap.add_argument("--build-L", type=int, default=48)
     ap.add_argument("--build-Msq", type=int, default=48)
     ap.add_argument("--build-Mpj", type=int, default=24)
     ap.add_argument("--build-Llearn", type=int, default=128)
-    ap.add_argument("--build-rounds", type=int, default=5)
+    ap.add_argument("--build-rounds", type=int, default=3)
+    ap.add_argument("--build-supply", type=int, default=0)
+    ap.add_argument("--build-supplyL", type=int, default=64)
+    ap.add_argument("--build-Llast", type=int, default=0)
+    ap.add_argument("--max-L", type=int, default=2000)
     ap.add_argument("--exact-knn", action="store_true", help="exact learn->base kNN lists (torch brute force)")
     ap.add_argument("--build-phase1-ip", action="store_true", help="phase 1 by the index metric instead of L2")
     ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/4)")
@@ -131,7 +135,8 @@ def main():
     idx.BuildBootstrapGraph(M=args.build_M, base_cap=args.build_basecap, max_degree=args.build_maxdeg,
                             L_build=args.build_L, learn=learn if n_learn else None, M_sq=args.build_Msq,
                             M_pj=args.build_Mpj, L_learn=args.build_Llearn, rounds=args.build_rounds,
-                            phase1_l2=not args.build_phase1_ip, learn_knn=learn_knn)
+                            phase1_l2=not args.build_phase1_ip, learn_knn=learn_knn, supply_k=args.build_supply,
+                            supply_L=args.build_supplyL, L_learn_last=args.build_Llast)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
@@ -156,7 +161,7 @@ def main():
     chosen = args.L
     if chosen == 0 or args.sweep:
         for L in L_LIST:
-            if L < args.k:
+            if L < args.k or L > args.max_L:
                 continue
             o = run(L)
             torch.cuda.synchronize()
@@ -282,7 +287,7 @@ def cpu_baseline(np, torch, idx, base, myq, out, args, L):
     log(f"[cpu] host copies of base + graph in {time.time() - t0:.1f}s; impl={impl}")
     threads = oracle.max_threads(impl)
     dpad = idx.info("dim_padded")
-    oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, 1, threads=1, impl=impl, dim=dpad)  # warm-up
+    oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, 1, threads=threads, impl=impl, dim=dpad)  # warm-up
     done, spent, reps, res = 0, 0.0, 0, None
     while spent < args.cpu_seconds and reps < 50:
         t0 = time.perf_counter()

@@ -105,6 +105,10 @@ typedef struct roar_build_params {
     const uint32_t *learn_knn_dev; /* optional exact learn->base kNN ids in HBM, [n_learn][M_sq], nearest first:
                                       the input of the reference builder (LoadLearnBaseKNN,
                                       src/index_bipartite.cpp:2622-2639); projected before the search rounds */
+    uint32_t supply_k;   /* phase 3: link every node with its supply_k nearest (index metric) found by
+                            searching the finished graph with the node's own vector; 0 = skip */
+    uint32_t supply_L;
+    uint32_t L_learn_last; /* pool length of the last projection round (0 = L_learn) */
 } roar_build_params;
 int roar_build_graph(roar_index *idx, const roar_build_params *params);
 

@@ -29,7 +29,8 @@ class BuildParams(C.Structure):
     _fields_ = [("M", C.c_uint32), ("base_cap", C.c_uint32), ("max_degree", C.c_uint32), ("L_build", C.c_uint32),
                 ("max_batch", C.c_uint64), ("learn_dev", C.c_void_p), ("n_learn", C.c_uint64),
                 ("learn_stride_floats", C.c_uint32), ("M_sq", C.c_uint32), ("M_pj", C.c_uint32),
-                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("learn_knn_dev", C.c_void_p)]
+                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
+                ("L_learn_last", C.c_uint32)]
 
 
 class RoarError(RuntimeError):

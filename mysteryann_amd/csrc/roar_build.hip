@@ -248,6 +248,44 @@ __global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32
     }
 }
 
+// connectivity supplement (cf. the reference's "connectivity enhancement", src/index_bipartite.cpp:
+// 1188-1262): node v was searched in the finished graph with its own vector under the index
+// metric; link v <-> each of its first Kc results where rows have room (thread per node).
+__global__ void supply_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count,
+                              const uint32_t *__restrict__ res, uint32_t M, uint32_t Kc, uint32_t *indeg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t v = a + i;
+    uint32_t *vrow = adj + (u64)v * S;
+    uint32_t done = 0;
+    for (uint32_t j = 0; j < M && done < Kc; ++j) {
+        const uint32_t u = res[(u64)i * M + j];
+        if (u == 0xFFFFFFFFu || u == v) continue;
+        done++;
+        uint32_t *urow = adj + (u64)u * S;
+        {   // u -> v
+            const uint32_t ud = urow[0] < max_deg ? urow[0] : max_deg;
+            bool have = false;
+            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == v;
+            if (!have) {
+                const uint32_t old = atomicAdd(&urow[0], 1u);
+                if (old < max_deg) { urow[1 + old] = v; atomicAdd(&indeg[v], 1u); }
+                else atomicSub(&urow[0], 1u);
+            }
+        }
+        {   // v -> u
+            const uint32_t vd = vrow[0] < max_deg ? vrow[0] : max_deg;
+            bool have = false;
+            for (uint32_t q = 0; q < vd; ++q) have |= vrow[1 + q] == u;
+            if (!have) {
+                const uint32_t old = atomicAdd(&vrow[0], 1u);
+                if (old < max_deg) { vrow[1 + old] = u; atomicAdd(&indeg[u], 1u); }
+                else atomicSub(&vrow[0], 1u);
+            }
+        }
+    }
+}
+
 __global__ void snapshot_degree_kernel(const uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n, uint32_t *base_deg) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
@@ -364,6 +402,14 @@ int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t 
         hipLaunchKernelGGL(project_prune_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, max_deg,
                            base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt);
     }
+    return (int)hipGetLastError();
+}
+
+int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+                   uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(supply_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, adj, S, max_deg, a,
+                       count, res, M, Kc, indeg);
     return (int)hipGetLastError();
 }
 

@@ -23,6 +23,8 @@ int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32
 int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, const float *base,
                     uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C,
                     uint32_t Mp, uint32_t *indeg, uint32_t salt, void *stream);
+int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+                   uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream);
 int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
                             void *stream);
 int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
@@ -552,7 +554,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     uint64_t max_batch = bp->max_batch ? bp->max_batch : (1u << 19);
     max_batch = std::min<uint64_t>(max_batch, std::max<uint64_t>(n, n_learn));
     const uint64_t cap = std::max<uint64_t>(max_batch, 1025);
-    const uint32_t K = std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u);  // result row width
+    const uint32_t K = std::max(std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u), bp->supply_k + 1);  // result row width
     if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
     uint32_t *res_ids = nullptr, *indeg = nullptr, *scratch = nullptr, *base_deg = nullptr;
     float *res_d = nullptr, *sums = nullptr;
@@ -620,12 +622,24 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     for (uint32_t r = 0; r < rounds && n_learn; ++r) {
         for (uint64_t a = 0; a < n_learn; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, n_learn - a);
-            if ((e = search(bp->learn_dev + a * bp->learn_stride_floats, cnt, bp->learn_stride_floats, C, L_learn))) {
+            const uint32_t Lr = (r + 1 == rounds && bp->L_learn_last > L_learn) ? bp->L_learn_last : L_learn;
+            if ((e = search(bp->learn_dev + a * bp->learn_stride_floats, cnt, bp->learn_stride_floats, C, Lr))) {
                 cleanup();
                 return e;
             }
             BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
                                    (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), nullptr));
+            BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+        }
+    }
+    // phase 3: connectivity supplement in the index metric
+    if (bp->supply_k) {
+        const uint32_t Ks = std::min<uint32_t>(bp->supply_k, K);
+        const uint32_t Ls = std::max<uint32_t>(bp->supply_L, Ks);
+        for (uint64_t a = 0; a < n; a += max_batch) {
+            const uint64_t cnt = std::min<uint64_t>(max_batch, n - a);
+            if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
+            BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }

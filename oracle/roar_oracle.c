@@ -249,21 +249,36 @@ int oracle_search_batch(const float *base, uint64_t n, uint64_t stride, uint32_t
 #else
     threads = 1;
 #endif
+    /* one visited list per thread, kept across calls like the reference's pool
+     * (InitVisitedListPool once per index, outside the timed loop) */
+    static oracle_visited *g_vl = NULL;
+    static int g_threads = 0;
+    static uint64_t g_n = 0;
+    if (!g_vl || g_threads != threads || g_n != n) {
+        for (int t = 0; g_vl && t < g_threads; ++t) free(g_vl[t].mass);
+        free(g_vl);
+        g_vl = (oracle_visited *)calloc((size_t)threads, sizeof(oracle_visited));
+        for (int t = 0; t < threads; ++t) visited_init(&g_vl[t], n);
+        g_threads = threads;
+        g_n = n;
+    }
 #pragma omp parallel num_threads(threads) reduction(+ : short_count)
     {
-        oracle_visited vl;
+#ifdef _OPENMP
+        oracle_visited *vlp = &g_vl[omp_get_thread_num()];
+#else
+        oracle_visited *vlp = &g_vl[0];
+#endif
         oracle_pq q;
-        visited_init(&vl, n);
         oracle_pq_init(&q, L);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t i = 0; i < (int64_t)nq; ++i) {
             uint32_t sc = 0;
             int rc = search_one(base, stride, dim, metric, offsets, nbrs, ep, queries + (uint64_t)i * qstride, k, L,
-                                &vl, &q, ids + (uint64_t)i * k, dists + (uint64_t)i * k, &cmps[i], &hops[i], &sc);
+                                vlp, &q, ids + (uint64_t)i * k, dists + (uint64_t)i * k, &cmps[i], &hops[i], &sc);
             if (scanned) scanned[i] = sc;
             if (rc) short_count++;
         }
-        free(vl.mass);
         oracle_pq_free(&q);
     }
     return short_count;

@@ -1,0 +1,60 @@
+"""Condense a gpurun_out/<round>/ rocprofv3 capture (scripts/profile_r1.sh) into the small files
+committed under profiles/: kernel stats, the search kernel's per-launch durations, and the HBM
+traffic counters with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B lines
+at 64 B -> x2; calibrated on this kernel's own access pattern by scripts/calib.sh)."""
+import csv, glob, json, os, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(out, exist_ok=True)
+bench = json.load(open(os.path.join(src, "bench.json")))
+Lchosen = bench["config"]["L_pq"]
+
+
+def search_rows(path):
+    rows = [r for r in csv.DictReader(open(path)) if "roar_search_kernel<1, true" in r["Kernel_Name"]]
+    return rows
+
+
+# 1. kernel stats (top 12 rows, names shortened)
+stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0])))
+with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --L %d\n" % Lchosen)
+    f.write("# (whole process: data generation, graph build, ground truth, L sweep is skipped with --L)\n")
+    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+    for r in stats[:12]:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = name.split("(")[0][-80:] if "Cijk" not in name else "hipBLASLt GEMM (ground truth, torch)"
+        f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+
+# 2. per-launch durations of the timed steps: the last 5+1+... launches of the IP search kernel at 10 000 queries
+trace = search_rows(glob.glob(os.path.join(src, "trace/*/*_kernel_trace.csv"))[0])
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace]
+timed = durs[-5:]
+# 3. PMC
+def pmc(name):
+    rows = search_rows(glob.glob(os.path.join(src, f"{name}/*/*_counter_collection.csv"))[0])
+    return [float(r["Counter_Value"]) for r in rows][-5:], [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows][-5:]
+fetch, fd = pmc("pmc_fetch")
+write, wd = pmc("pmc_write")
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+fetch_b = sum(fetch) / len(fetch) * 1024 * 2  # KB -> B, x2 gfx950 correction (calibrated 0.5658 x 2 = 1.1316 = 905 B per 800-B row)
+write_b = sum(write) / len(write) * 1024
+summary = {
+    "command": f"python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --L {Lchosen}",
+    "kernel": "roar_search_kernel<VIS_LDS, IP, NCH=12> (D=200)",
+    "timed_launch_durations_ns": timed,
+    "avg_launch_ms_rocprof": sum(timed) / len(timed) / 1e6,
+    "avg_launch_ms_bench_hip_events": bench["roofline"]["kernel_ms"],
+    "FETCH_SIZE_KB_raw_per_launch": sum(fetch) / len(fetch),
+    "WRITE_SIZE_KB_raw_per_launch": sum(write) / len(write),
+    "hbm_traffic_bytes_per_launch_corrected": fetch_b + write_b,
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+    "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); calibrated on this access pattern: "
+                  "distance-only kernel over uniformly random 800-B rows of an 8 GB table reads FETCH_SIZE*1024 = 0.5658 x known bytes "
+                  "(= 7 lines x 128 B / 800 B / 2), see profiles/%s_fetch_calibration.txt" % tag,
+    "bench_line": bench,
+}
+json.dump(summary, open(os.path.join(out, f"{tag}_search_kernel_summary.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1))

@@ -263,6 +263,21 @@ def main():
                      "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids},
     }
 
+    # HBM traffic per launch comes from a separate rocprofv3 --pmc capture of this same command
+    # (scripts/profile_r1.sh -> profiles/*_search_kernel_summary.json); quoted only when it matches.
+    try:
+        import glob
+
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_search_kernel_summary.json")))[::-1]:
+            s = json.load(open(f))
+            c = s["bench_line"]["config"]
+            if c["workload"] == result["config"]["workload"] and c["L_pq"] == chosen and c["index"] == result["config"]["index"]:
+                result["roofline"]["traffic"] = s["hbm_traffic_bytes_per_launch_corrected"]
+                result["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
+                break
+    except Exception as e:  # noqa: BLE001
+        log(f"[rank {rank}] no PMC traffic figure: {e}")
+
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(np, torch, idx, base, myq, out, args, chosen)
 
@@ -270,6 +285,18 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def effective_cpus():
+    """Host cores this process may really use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(np, torch, idx, base, myq, out, args, L):
@@ -285,7 +312,10 @@ def cpu_baseline(np, torch, idx, base, myq, out, args, L):
     if hq.shape[1] != hb.shape[1]:
         hq = np.ascontiguousarray(np.pad(hq, ((0, 0), (0, hb.shape[1] - hq.shape[1]))))
     log(f"[cpu] host copies of base + graph in {time.time() - t0:.1f}s; impl={impl}")
-    threads = oracle.max_threads(impl)
+    # the GPU box runs this container under a cgroup CPU quota (16 of the host's 256 hardware threads at
+    # the time of writing): more threads than the quota only thrash, so use exactly the quota.  16 is
+    # also the reference's canonical -T (run_roargraph_search_test.sh:1).
+    threads = min(oracle.max_threads(impl), effective_cpus())
     dpad = idx.info("dim_padded")
     oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, 1, threads=threads, impl=impl, dim=dpad)  # warm-up
     done, spent, reps, res = 0, 0.0, 0, None
@@ -301,6 +331,7 @@ def cpu_baseline(np, torch, idx, base, myq, out, args, L):
     return {"value": done / spent, "unit": "queries/s", "cores": threads,
             "kind": "reference" if impl == "ref" else "port",
             "sample": f"all {hq.shape[0]} queries x {reps} passes at L_pq={L}, omp dynamic,1 over {threads} threads "
+                      f"(= cgroup CPU quota; host has {os.cpu_count()} hardware threads) "
                       f"({'reference distance/queue/visited headers compiled in place, search loop restated' if impl == 'ref' else 'C restatement'})",
             "gpu_vs_cpu_ids_identical_fraction": ids_equal,
             "gpu_vs_cpu_max_abs_dist_diff": float(np.abs(gpu_d - res["dists"]).max())}

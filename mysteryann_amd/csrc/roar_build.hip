@@ -322,6 +322,23 @@ __global__ void rescue_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n
     atomicAdd(&indeg[v], 1u);
 }
 
+// final clean-up of a built graph: drop self loops and repeated neighbours (first occurrence kept,
+// order preserved), so rows hold distinct ids like the rows made from a file (roar_set_graph_csr).
+__global__ void dedupe_rows_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t *row = adj + v * S;
+    const uint32_t deg = row[0] < max_deg ? row[0] : max_deg;
+    uint32_t out = 0;
+    for (uint32_t j = 0; j < deg; ++j) {
+        const uint32_t u = row[1 + j];
+        bool dup = u == (uint32_t)v;
+        for (uint32_t q = 0; q < out && !dup; ++q) dup = row[1 + q] == u;
+        if (!dup) row[1 + out++] = u;
+    }
+    row[0] = out;
+}
+
 __global__ void degree_stats_kernel(const uint32_t *adj, uint32_t S, u64 n, u64 *sum, uint32_t *maxd) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t d = v < n ? adj[v * S] : 0u;
@@ -342,6 +359,12 @@ __global__ void degree_stats_kernel(const uint32_t *adj, uint32_t S, u64 n, u64 
 }  // namespace
 
 extern "C" {
+
+int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream) {
+    hipLaunchKernelGGL(dedupe_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
+                       max_deg, (u64)n);
+    return (int)hipGetLastError();
+}
 
 int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
                          void *stream) {

@@ -30,6 +30,7 @@ int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, u
 int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
 int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
                    uint32_t *orphans, void *stream);
+int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
 int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
                          void *stream);
 }
@@ -650,6 +651,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         HIP_TRY(hipMemcpy(&orphans, scratch, 4, hipMemcpyDeviceToHost));
         if (orphans == 0) break;
     }
+    BK_TRY(roar_bk_dedupe(idx->adj, S, max_degree, n, nullptr));
     BK_TRY(roar_bk_degree_stats(idx->adj, S, n, (unsigned long long *)scratch, scratch + 2, nullptr));
     unsigned long long st[2] = {0, 0};
     HIP_TRY(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));

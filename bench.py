@@ -40,8 +40,8 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048):
-    """Exact top-k by inner product (max dot), ids only.  Test infrastructure (torch matmul)."""
+def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048, l2=False):
+    """Exact top-k by inner product (max dot) or L2, ids only.  Test infrastructure (torch matmul)."""
     nq = queries.shape[0]
     out = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
     for q0 in range(0, nq, chunk_q):
@@ -49,7 +49,10 @@ def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048)
         best_v = torch.full((q.shape[0], k), -float("inf"), device=q.device)
         best_i = torch.zeros((q.shape[0], k), dtype=torch.int64, device=q.device)
         for r0 in range(0, base.shape[0], chunk_rows):
-            s = q @ base[r0:r0 + chunk_rows, :d].T
+            blk = base[r0:r0 + chunk_rows, :d]
+            s = q @ blk.T
+            if l2:  # -(|x|^2 - 2 q.x): larger is nearer
+                s = 2 * s - (blk * blk).sum(dim=1)[None, :]
             v, i = torch.topk(s, k, dim=1)
             v = torch.cat([best_v, v], 1)
             i = torch.cat([best_i, i + r0], 1)
@@ -69,9 +72,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000, help="base points (10 M = the BASELINE config)")
+    ap.add_argument("--workload", default="t2i", choices=["t2i", "webvid", "sift"],
+                    help="t2i = the BASELINE metric's configuration (default); webvid / sift = the other configs' shapes")
+    ap.add_argument("--n", type=int, default=0, help="base points (default: 10 M t2i, 2.5 M webvid, 1 M sift)")
     ap.add_argument("--nq", type=int, default=10_000)
-    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--L", type=int, default=0, help="0 = smallest L_pq of the reference sweep with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.9)
@@ -93,6 +98,8 @@ def main():
     ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
+    ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
     ap.add_argument("--sweep", action="store_true", help="print the whole L_pq curve (CSV columns of the reference)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -100,16 +107,20 @@ def main():
     import numpy as np
     import torch
 
+    shape = {"t2i": (10_000_000, 200), "webvid": (2_500_000, 512), "sift": (1_000_000, 128)}[args.workload]
+    args.n = args.n or shape[0]
+    args.dim = args.dim or shape[1]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
     torch.cuda.set_device(local)
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
 
     from mysteryann_amd import index as mi
@@ -117,13 +128,15 @@ def main():
 
     t0 = time.time()
     n_learn = args.learn if args.learn >= 0 else max(args.n // 4, 1000)
-    base, queries, learn = synth.t2i_torch(args.n, args.nq, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
-                                           query_seed=args.seed + 2 + 1000 * rank)
+    gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch}[args.workload]
+    base, queries, learn = gen(args.n, args.nq, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
+                               query_seed=args.seed + 2 + 1000 * rank)
+    metric = mi.L2 if args.workload == "sift" else mi.INNER_PRODUCT
     torch.cuda.synchronize()
     log(f"[rank {rank}] synthetic T2I-shape data: base {tuple(base.shape)}, queries {tuple(queries.shape)}, "
         f"learn {n_learn} in {time.time() - t0:.1f}s")
 
-    idx = mi.IndexBipartite(args.dim, args.n, mi.INNER_PRODUCT, None, device=local)
+    idx = mi.IndexBipartite(args.dim, args.n, metric, None, device=local)
     idx.SetBaseData(base)
     learn_knn = None
     if args.exact_knn and n_learn:
@@ -147,11 +160,13 @@ def main():
     lo, hi = 0, args.nq
     myq = queries
     t0 = time.time()
-    gt = brute_force_gt(torch, base, args.dim, myq, args.k)
+    gt = brute_force_gt(torch, base, args.dim, myq, args.k, l2=(metric == mi.L2))
     torch.cuda.synchronize()
     log(f"[rank {rank}] brute-force ground truth for {hi - lo} queries in {time.time() - t0:.1f}s")
 
     idx.set_option("visited_mode", 1 if args.visited == "lds" else 0)
+    if args.vis_entries:
+        idx.set_option("vis_entries", args.vis_entries)
 
     def run(L, out=None):
         return idx.SearchRoarGraphBatchDevice(myq, args.k, L, out=out)
@@ -166,7 +181,7 @@ def main():
             o = run(L)
             torch.cuda.synchronize()
             r = recall_at_k(torch, o["ids"], gt, args.k)
-            if world > 1:
+            if use_dist:
                 t = torch.tensor([r * (hi - lo)], device=dev, dtype=torch.float64)
                 dist.all_reduce(t)
                 r = t.item() / (args.nq * world)
@@ -187,6 +202,15 @@ def main():
         for row in curve:
             log(",".join(f"{v:.6g}" for v in row))
 
+    if args.tune:
+        for ve in (1024, 2048, 4096, 8192, 16384, 32768):
+            idx.set_option("vis_entries", ve)
+            for _ in range(2):
+                o = run(chosen)
+            torch.cuda.synchronize()
+            log(f"[tune] L_pq={chosen} vis_entries={ve}: kernel {idx.info('last_kernel_ns') / 1e6:.3f} ms, "
+                f"cmps {float(o['cmps'].float().mean()):.0f}, grid {idx.info('last_grid')}, lds {idx.info('last_lds_bytes')}")
+        idx.set_option("vis_entries", args.vis_entries)
     out = run(chosen)
     torch.cuda.synchronize()
     rec = recall_at_k(torch, out["ids"], gt, args.k)
@@ -205,7 +229,7 @@ def main():
     for _ in range(args.warmup):
         run(chosen, out)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -215,13 +239,13 @@ def main():
         run(chosen, out)
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     gpu_ms = e0.elapsed_time(e1)  # same stream as the launches (torch's current stream is passed down)
     last_kernel_ms = idx.info("last_kernel_ns") * 1e-6
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
@@ -234,7 +258,8 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     result = {
-        "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD",
+        "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD" if args.workload == "t2i"
+        else f"QPS @ recall@10={args.target_recall}, {args.workload} shape",
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -246,8 +271,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "t2i-10M-ip" if args.n == 10_000_000 else f"t2i-shape-n{args.n}", "n_base": args.n,
-                   "dim": args.dim, "metric": "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
+        "config": {"workload": "t2i-10M-ip" if (args.workload, args.n) == ("t2i", 10_000_000)
+                   else f"{args.workload}-shape-n{args.n}", "n_base": args.n,
+                   "dim": args.dim, "metric": "l2" if metric == mi.L2 else "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
                    "recall_at_10": rec, "parallelism": f"query batches sharded over {world} GPU(s), index replicated, no collective",
                    "visited": args.visited, "index": f"bootstrap M={args.build_M} cap={args.build_basecap}/{args.build_maxdeg} "
                                                       f"L={args.build_L}; projection learn={n_learn} Msq={args.build_Msq} "
@@ -279,11 +305,11 @@ def main():
         log(f"[rank {rank}] no PMC traffic figure: {e}")
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(np, torch, idx, base, myq, out, args, chosen)
+        result["cpu_baseline"] = cpu_baseline(np, torch, idx, base, myq, out, args, chosen, metric)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -299,7 +325,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(np, torch, idx, base, myq, out, args, L):
+def cpu_baseline(np, torch, idx, base, myq, out, args, L, metric):
     """The reference's loop shape (100 warm-up queries, then omp parallel for schedule(dynamic,1),
     tests/test_search_roargraph.cpp:198-212) on the host cores, same graph, same queries."""
     import oracle
@@ -317,11 +343,11 @@ def cpu_baseline(np, torch, idx, base, myq, out, args, L):
     # also the reference's canonical -T (run_roargraph_search_test.sh:1).
     threads = min(oracle.max_threads(impl), effective_cpus())
     dpad = idx.info("dim_padded")
-    oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, 1, threads=threads, impl=impl, dim=dpad)  # warm-up
+    oracle.search_batch(hb, off, nbrs, ep, hq[:100], args.k, L, metric, threads=threads, impl=impl, dim=dpad)  # warm-up
     done, spent, reps, res = 0, 0.0, 0, None
     while spent < args.cpu_seconds and reps < 50:
         t0 = time.perf_counter()
-        res = oracle.search_batch(hb, off, nbrs, ep, hq, args.k, L, 1, threads=threads, impl=impl, dim=dpad)
+        res = oracle.search_batch(hb, off, nbrs, ep, hq, args.k, L, metric, threads=threads, impl=impl, dim=dpad)
         spent += time.perf_counter() - t0
         done += hq.shape[0]
         reps += 1

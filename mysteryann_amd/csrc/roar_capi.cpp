@@ -220,8 +220,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
     if (idx->visited_mode == ROAR_VISITED_LDS) {
+        // auto: ~64 tags per pool slot, but never so large that fewer than 8 waves fit a CU (measured:
+        // 8192 entries is the optimum at L_pq = 75 on T2I-10M, 4096-8192 at L_pq = 240 on the SIFT
+        // shape; a smaller table only re-scores a few nodes, a larger one halves the occupancy)
         uint32_t want = idx->vis_entries > 0 ? (uint32_t)idx->vis_entries : 64u * L;
-        if (idx->vis_entries <= 0) want = std::min(std::max(want, 2048u), 16384u);
+        if (idx->vis_entries <= 0) want = std::min(std::max(want, 2048u), L >= 512 ? 16384u : 8192u);
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
         while ((1u << sets_log2) < sets) sets_log2++;

@@ -95,3 +95,34 @@ def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, 
     q = queries(nq, seed + 2 if query_seed is None else query_seed)
     learn = queries(n_learn, seed + 3) if n_learn else None
     return base, q, learn
+
+
+def webvid_torch(n, nq, d=512, seed=1234, n_learn=0, device="cuda", query_seed=None):
+    """WebVid shape: unit-norm rows (prepare_for_clip_webvid.py:92-98), unit-norm shifted queries."""
+    import torch
+
+    base, q, learn = t2i_torch(n, nq, d, seed, n_learn, device, query_seed=query_seed)
+    base /= base.norm(dim=1, keepdim=True)
+    q /= q.norm(dim=1, keepdim=True)
+    if learn is not None:
+        learn /= learn.norm(dim=1, keepdim=True)
+    return base, q, learn
+
+
+def sift_torch(n, nq, d=128, seed=1234, n_learn=0, device="cuda", query_seed=None):
+    """SIFT shape: non-negative integer-valued floats 0..255 around 64 cluster centres, L2."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    centers = torch.randn((64, d), generator=g, device=device).abs() * 40
+
+    def draw(m, sd):
+        g.manual_seed(sd)
+        c = centers[torch.randint(0, 64, (m,), generator=g, device=device)]
+        return torch.clamp(torch.round(c + torch.randn((m, d), generator=g, device=device).abs() * 20), 0, 255)
+
+    base = draw(n, seed + 1)
+    q = draw(nq, seed + 2 if query_seed is None else query_seed)
+    learn = draw(n_learn, seed + 3) if n_learn else None
+    return base, q, learn

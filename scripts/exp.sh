@@ -1,4 +1,6 @@
-for cfg in "--build-M 16 --build-basecap 64 --build-maxdeg 128 --learn 2500000 --build-rounds 5" "--build-M 20 --build-basecap 80 --build-maxdeg 128 --learn 2500000 --build-rounds 3" "--build-M 16 --build-basecap 64 --build-maxdeg 128 --learn 5000000 --build-rounds 3 --build-Msq 64 --build-Mpj 32" ; do
-echo "== $cfg"
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweep --max-L 200 $cfg 2>&1 | grep -E "exact learn|bootstrap graph|L_pq= *(10|20|30|40|50|60|70|80|100|150|200) " | cut -c1-400
-done
+echo "== torchrun nproc 1"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>gpurun_out/tr.err | cut -c1-700; tail -3 gpurun_out/tr.err
+echo "== webvid"
+python bench.py --workload webvid --steps 5 --warmup 2 --cpu-seconds 5 2>gpurun_out/wv.err | cut -c1-2500; grep -E "bootstrap|L_pq=" gpurun_out/wv.err | tail -8
+echo "== sift"
+python bench.py --workload sift --steps 5 --warmup 2 --cpu-seconds 5 2>gpurun_out/sf.err | cut -c1-2500; grep -E "bootstrap|L_pq=" gpurun_out/sf.err | tail -8

@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--L", type=int, default=0, help="0 = smallest L_pq of the reference sweep with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.9)
-    ap.add_argument("--visited", default="lds", choices=["lds", "exact"])
+    ap.add_argument("--visited", default="auto", choices=["auto", "lds", "exact"])
     ap.add_argument("--build-M", type=int, default=16)
     ap.add_argument("--build-basecap", type=int, default=64)
     ap.add_argument("--build-maxdeg", type=int, default=128)
@@ -93,7 +93,9 @@ def main():
     ap.add_argument("--build-supplyL", type=int, default=64)
     ap.add_argument("--build-Llast", type=int, default=0)
     ap.add_argument("--max-L", type=int, default=2000)
-    ap.add_argument("--exact-knn", action="store_true", help="exact learn->base kNN lists (torch brute force)")
+    ap.add_argument("--exact-knn", type=int, default=0,
+                    help="exact learn->base kNN lists (MFMA brute force) for the first N training queries")
+    ap.add_argument("--torch-gt", action="store_true", help="ground truth by torch matmul+topk instead of the MFMA generator")
     ap.add_argument("--build-phase1-ip", action="store_true", help="phase 1 by the index metric instead of L2")
     ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,12 +141,12 @@ def main():
     idx = mi.IndexBipartite(args.dim, args.n, metric, None, device=local)
     idx.SetBaseData(base)
     learn_knn = None
-    if args.exact_knn and n_learn:
-        t0 = time.time()
-        learn_knn = brute_force_gt(torch, base, args.dim, learn, args.build_Msq).to(torch.int32).contiguous()
-        torch.cuda.synchronize()
-        log(f"[rank {rank}] exact learn->base kNN ({n_learn} x {args.build_Msq}) in {time.time() - t0:.1f}s")
     t0 = time.time()
+    if args.exact_knn and n_learn:
+        ne = min(args.exact_knn, n_learn)
+        learn_knn, _ = idx.ExactKnnDevice(learn[:ne], args.build_Msq, want_dists=False)
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] exact learn->base kNN ({ne} x {args.build_Msq}, MFMA generator) in {time.time() - t0:.1f}s")
     idx.BuildBootstrapGraph(M=args.build_M, base_cap=args.build_basecap, max_degree=args.build_maxdeg,
                             L_build=args.build_L, learn=learn if n_learn else None, M_sq=args.build_Msq,
                             M_pj=args.build_Mpj, L_learn=args.build_Llearn, rounds=args.build_rounds,
@@ -160,11 +162,16 @@ def main():
     lo, hi = 0, args.nq
     myq = queries
     t0 = time.time()
-    gt = brute_force_gt(torch, base, args.dim, myq, args.k, l2=(metric == mi.L2))
+    if args.torch_gt:
+        gt = brute_force_gt(torch, base, args.dim, myq, args.k, l2=(metric == mi.L2))
+    else:  # the repo's own exact-kNN generator (f32 MFMA), SURVEY 8(f) #2
+        gt = idx.ExactKnnDevice(myq, args.k, want_dists=False)[0].to(torch.int64)
     torch.cuda.synchronize()
-    log(f"[rank {rank}] brute-force ground truth for {hi - lo} queries in {time.time() - t0:.1f}s")
+    log(f"[rank {rank}] brute-force ground truth for {hi - lo} queries in {time.time() - t0:.1f}s "
+        f"({'torch' if args.torch_gt else 'roar_exact_knn_device'})")
 
-    idx.set_option("visited_mode", 1 if args.visited == "lds" else 0)
+    VIS = {"exact": 0, "lds": 1, "auto": 2}
+    idx.set_option("visited_mode", VIS[args.visited])
     if args.vis_entries:
         idx.set_option("vis_entries", args.vis_entries)
 
@@ -219,7 +226,7 @@ def main():
     idx.set_option("visited_mode", 0)
     ex = run(chosen)
     torch.cuda.synchronize()
-    idx.set_option("visited_mode", 1 if args.visited == "lds" else 0)
+    idx.set_option("visited_mode", VIS[args.visited])
     dpad = idx.info("dim_padded")
     alg_bytes = (4 * dpad * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum() + 8 * ex["hops"].double().sum()
                  + (4 * dpad + 8 * args.k) * (hi - lo)).item()
@@ -275,7 +282,7 @@ def main():
                    else f"{args.workload}-shape-n{args.n}", "n_base": args.n,
                    "dim": args.dim, "metric": "l2" if metric == mi.L2 else "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
                    "recall_at_10": rec, "parallelism": f"query batches sharded over {world} GPU(s), index replicated, no collective",
-                   "visited": args.visited, "index": f"bootstrap M={args.build_M} cap={args.build_basecap}/{args.build_maxdeg} "
+                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")], "index": f"bootstrap M={args.build_M} cap={args.build_basecap}/{args.build_maxdeg} "
                                                       f"L={args.build_L}; projection learn={n_learn} Msq={args.build_Msq} "
                                                       f"Mpj={args.build_Mpj} L={args.build_Llearn} x{args.build_rounds}",
                    "avg_degree": idx.info("nedges") / args.n, "build_seconds": build_s},

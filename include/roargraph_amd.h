@@ -39,7 +39,7 @@ enum {
  *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
  *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
  *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1 };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: LDS for L_pq < 512, EXACT beyond */ };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -102,7 +102,8 @@ typedef struct roar_build_params {
     uint32_t L_learn;    /* pool length of the phase-2 searches */
     uint32_t rounds;     /* passes over the training queries */
     uint32_t phase1_l2;  /* 1: phase 1 links base points by L2 whatever the index metric is */
-    const uint32_t *learn_knn_dev; /* optional exact learn->base kNN ids in HBM, [n_learn][M_sq], nearest first:
+    uint64_t n_knn;      /* rows of learn_knn_dev */
+    const uint32_t *learn_knn_dev; /* optional exact learn->base kNN ids in HBM, [n_knn][M_sq], nearest first:
                                       the input of the reference builder (LoadLearnBaseKNN,
                                       src/index_bipartite.cpp:2622-2639); projected before the search rounds */
     uint32_t supply_k;   /* phase 3: link every node with its supply_k nearest (index metric) found by
@@ -141,6 +142,18 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
 int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats,
                    const uint32_t *ids, uint32_t m, float *out);
 
+/* ---- exact kNN generator ---------------------------------------------------------
+ * Producer of the two exact-kNN inputs the reference consumes but cannot make itself (their tool
+ * lived in the empty thirdparty/DiskANN submodule): the query->base ground truth read by
+ * load_gt_meta / load_gt_data_with_dist (include/efanna2e/util.h:84-155) and the learn->base
+ * top-M_sq lists read by LoadLearnBaseKNN (src/index_bipartite.cpp:2622-2639).  Brute force over the
+ * loaded base rows with the index metric: f32 MFMA GEMM + threshold top-k, ids sorted by
+ * (distance, id); distances are reference-signed (IP: negated dot; L2: squared, via |q|^2 - 2qx + |x|^2,
+ * so they agree with DistanceL2::compare to rounding, not bit for bit).  Device buffers; k <= 128;
+ * dists_dev may be NULL.  Synchronises the stream before returning. */
+int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                          uint32_t *ids_dev, float *dists_dev, void *hip_stream);
+
 /* ---- top-k merge for the index-sharded configuration ------------------------------------------
  * Not in the reference (new capability): merge `nshards` per-shard sorted top-k lists
  * per query by (distance, id) into a global top-k.  Device buffers laid out [shard][nq][k]. */
@@ -150,7 +163,7 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
 /* ---- options / introspection ----------------------------------------------------------------
  * Parameters::Set / Get  include/efanna2e/parameters.h:15-57 carry L_pq per call in the reference;
  * here L_pq is an argument and the remaining knobs are integers:
- *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS (default LDS)
+ *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_AUTO (default AUTO)
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq; power of two)
  *   "max_grid"       cap on the number of resident waves launched (0 = no cap)

@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libroargraph_amd.so")
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 4
-VISITED_EXACT, VISITED_LDS = 0, 1
+VISITED_EXACT, VISITED_LDS, VISITED_AUTO = 0, 1, 2
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_SHORT = 0, -1, -2, -3, -4, -5
 
 # every symbol include/roargraph_amd.h declares (checked by tests/test_capi_symbols.py)
@@ -20,6 +20,7 @@ SYMBOLS = [
     "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
     "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
     "roar_get_graph_csr", "roar_build_graph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
+    "roar_exact_knn_device",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
 ]
 
@@ -29,7 +30,7 @@ class BuildParams(C.Structure):
     _fields_ = [("M", C.c_uint32), ("base_cap", C.c_uint32), ("max_degree", C.c_uint32), ("L_build", C.c_uint32),
                 ("max_batch", C.c_uint64), ("learn_dev", C.c_void_p), ("n_learn", C.c_uint64),
                 ("learn_stride_floats", C.c_uint32), ("M_sq", C.c_uint32), ("M_pj", C.c_uint32),
-                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
+                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("n_knn", C.c_uint64), ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
                 ("L_learn_last", C.c_uint32)]
 
 
@@ -41,7 +42,7 @@ class RoarError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_capi.cpp", "roar_device.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_knn.hip", "roar_capi.cpp", "roar_device.h")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -85,6 +86,7 @@ def lib():
     l.roar_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                            vp, vp]
     l.roar_distances.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, C.c_uint32, fp]
+    l.roar_exact_knn_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp]
     l.roar_merge_topk_device.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
     l.roar_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]

@@ -35,6 +35,10 @@ int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned l
                          void *stream);
 }
 
+extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim,
+                            int ip, uint32_t k, uint32_t cap, void *cand, void *cursor, void *tau, void *bnorm,
+                            void *overflow_dev, uint32_t *ids, float *dists, uint32_t *overflowed, void *stream);
+
 namespace {
 
 thread_local std::string g_err;
@@ -77,7 +81,8 @@ struct roar_index {
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_nbrs;
     // options
-    int visited_mode = ROAR_VISITED_LDS;
+    int visited_mode = ROAR_VISITED_AUTO;
+    int last_mode = ROAR_VISITED_LDS;
     int waves_per_cu = 0;
     int vis_entries = 0;
     int max_grid = 0;
@@ -216,10 +221,16 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.nq = (uint32_t)nq;
     p.k = k;
     p.L = L;
+    // AUTO: the on-chip tag table while it still leaves 8 waves per CU (L_pq < 512), HBM epoch tags
+    // beyond (measured on T2I-10M: LDS 15.4 / 28.9 / 49.1 ms vs EXACT 19.3 / 33.3 / 50.7 ms at
+    // L_pq = 150 / 300 / 500, but 250 vs 126 ms at L_pq = 1500)
+    const int mode = idx->visited_mode == ROAR_VISITED_AUTO ? (L < 512 ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
+                                                            : idx->visited_mode;
+    idx->last_mode = mode;
     // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
-    if (idx->visited_mode == ROAR_VISITED_LDS) {
+    if (mode == ROAR_VISITED_LDS) {
         // auto: ~64 tags per pool slot, but never so large that fewer than 8 waves fit a CU (measured:
         // 8192 entries is the optimum at L_pq = 75 on T2I-10M, 4096-8192 at L_pq = 240 on the SIFT
         // shape; a smaller table only re-scores a few nodes, a larger one halves the occupancy)
@@ -247,7 +258,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.lds_bytes = off;
     if (p.lds_bytes > 160 * 1024) return fail(ROAR_ERR_ARG, "L_pq = %u needs %u bytes of LDS per query (max 163840)", L, off);
     int occ = 0;
-    int rc = roar_search_occupancy(idx->ip ? 1 : 0, idx->visited_mode, idx->dim_pad, p.lds_bytes, &occ);
+    int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, idx->dim_pad, p.lds_bytes, &occ);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
@@ -256,7 +267,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;
     if (grid == 0) grid = 1;
     plan->grid = (uint32_t)grid;
-    if (idx->visited_mode == ROAR_VISITED_EXACT) {
+    if (mode == ROAR_VISITED_EXACT) {
         int e = ensure_tags(idx, std::max<uint32_t>(plan->grid, idx->slots));
         if (e) return e;
         p.tags = idx->tags;
@@ -556,7 +567,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     idx->gn = n;
     idx->max_deg = max_degree;
     uint64_t max_batch = bp->max_batch ? bp->max_batch : (1u << 19);
-    max_batch = std::min<uint64_t>(max_batch, std::max<uint64_t>(n, n_learn));
+    max_batch = std::min<uint64_t>(max_batch, std::max<uint64_t>(n, std::max<uint64_t>(n_learn, bp->n_knn)));
     const uint64_t cap = std::max<uint64_t>(max_batch, 1025);
     const uint32_t K = std::max(std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u), bp->supply_k + 1);  // result row width
     if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
@@ -615,9 +626,9 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // phase 2: projection of the training queries, `rounds` times over the improving graph
     // exact learn -> base kNN lists (the reference builder's input, LoadLearnBaseKNN,
     // src/index_bipartite.cpp:2622-2639) are projected first when the caller has them
-    if (bp->learn_knn_dev && bp->n_learn) {
-        for (uint64_t a = 0; a < bp->n_learn; a += max_batch) {
-            const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_learn - a);
+    if (bp->learn_knn_dev && bp->n_knn) {
+        for (uint64_t a = 0; a < bp->n_knn; a += max_batch) {
+            const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_knn - a);
             BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
                                    (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
@@ -697,7 +708,7 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->visited_mode, plan.grid, st);
+    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -813,6 +824,58 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     return ROAR_OK;
 }
 
+int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                          uint32_t *ids_dev, float *dists_dev, void *hip_stream) {
+    if (!idx || !queries_dev || !ids_dev) return fail(ROAR_ERR_ARG, "bad kNN arguments");
+    if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "exact kNN before base vectors were loaded");
+    if (k == 0 || k > 128 || k > idx->n) return fail(ROAR_ERR_ARG, "k must be in 1..min(128, n)");
+    if (qstride_floats < idx->dim_pad || (qstride_floats & 3))
+        return fail(ROAR_ERR_ARG, "device queries need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
+    if (nq == 0) return ROAR_OK;
+    int e = use_device(idx);
+    if (e) return e;
+    uint32_t cap = 2048;
+    while (cap < 64u * k && cap < 8192) cap <<= 1;
+    const uint64_t chunk = std::min<uint64_t>(nq, 65536);
+    void *cand = nullptr, *cursor = nullptr, *tau = nullptr, *bnorm = nullptr, *ovf = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(cand); (void)hipFree(cursor); (void)hipFree(tau); (void)hipFree(bnorm); (void)hipFree(ovf);
+    };
+    HIP_TRY(hipMalloc(&cursor, chunk * 4));
+    HIP_TRY(hipMalloc(&tau, chunk * 4));
+    HIP_TRY(hipMalloc(&ovf, 4));
+    if (!idx->ip) HIP_TRY(hipMalloc(&bnorm, idx->n * 4));
+    for (;;) {
+        if (hipMalloc(&cand, chunk * cap * 8) != hipSuccess) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "out of device memory for the kNN candidate lists");
+        }
+        bool retry = false;
+        for (uint64_t q0 = 0; q0 < nq && !retry; q0 += chunk) {
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+            uint32_t overflowed = 0;
+            int rc = roar_knn_run(queries_dev + q0 * qstride_floats, qstride_floats, cnt, idx->base, idx->ld, idx->n,
+                                  idx->dim_pad, idx->ip ? 1 : 0, k, cap, cand, cursor, tau, bnorm, ovf, ids_dev + q0 * k,
+                                  dists_dev ? dists_dev + q0 * k : nullptr, &overflowed, hip_stream);
+            if (rc != 0) {
+                cleanup();
+                return fail(ROAR_ERR_DEVICE, "exact kNN kernels failed: %s", hipGetErrorString((hipError_t)rc));
+            }
+            if (overflowed) retry = true;
+        }
+        if (!retry) break;
+        (void)hipFree(cand);
+        cand = nullptr;
+        if (cap >= 8192) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "exact kNN candidate lists overflowed at the largest capacity");
+        }
+        cap <<= 1;
+    }
+    cleanup();
+    return ROAR_OK;
+}
+
 int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
                            const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream) {
     if (nshards == 0 || nshards > 32 || k == 0) return fail(ROAR_ERR_ARG, "merge needs 1..32 shards and k > 0");
@@ -830,7 +893,8 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     if (!idx || !key) return fail(ROAR_ERR_ARG, "bad arguments");
     std::string k(key);
     if (k == "visited_mode") {
-        if (value != ROAR_VISITED_EXACT && value != ROAR_VISITED_LDS) return fail(ROAR_ERR_ARG, "bad visited_mode");
+        if (value != ROAR_VISITED_EXACT && value != ROAR_VISITED_LDS && value != ROAR_VISITED_AUTO)
+            return fail(ROAR_ERR_ARG, "bad visited_mode");
         idx->visited_mode = (int)value;
     } else if (k == "waves_per_cu") {
         if (value < 0 || value > 32) return fail(ROAR_ERR_ARG, "waves_per_cu must be 0..32");
@@ -861,6 +925,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "n_cus") *value = idx->n_cus;
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
+    else if (k == "last_visited_mode") *value = idx->last_mode;
     else if (k == "last_grid") *value = idx->last_grid;
     else if (k == "last_lds_bytes") *value = idx->last_lds;
     else if (k == "last_vis_entries") *value = idx->last_vis_entries;

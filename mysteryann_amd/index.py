@@ -116,7 +116,7 @@ class IndexBipartite:
             bp.learn_dev, bp.n_learn, bp.learn_stride_floats = learn.data_ptr(), learn.shape[0], learn.shape[1]
         if learn_knn is not None:  # int32/uint32 CUDA tensor [n_learn, M_sq]
             assert learn_knn.is_cuda and learn_knn.is_contiguous() and learn_knn.shape[1] == M_sq
-            bp.learn_knn_dev, bp.n_learn = learn_knn.data_ptr(), learn_knn.shape[0]
+            bp.learn_knn_dev, bp.n_knn = learn_knn.data_ptr(), learn_knn.shape[0]
         capi.check(self._lib.roar_build_graph(self._h, C.byref(bp)))
 
     def InitVisitedListPool(self, num_threads):
@@ -182,6 +182,21 @@ class IndexBipartite:
             C.c_void_p(out["scanned"].data_ptr()), C.c_void_p(out["short"].data_ptr()),
             C.c_void_p(st.cuda_stream)))
         return out
+
+    def ExactKnnDevice(self, queries, k, want_dists=True, stream=None):
+        """Brute-force top-k of every query among the loaded base rows (roar_exact_knn_device): the
+        generator of ground-truth / learn->base kNN files.  queries: CUDA/HIP tensor [nq, stride]."""
+        import torch
+
+        nq = queries.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=queries.device) if want_dists else None
+        st = stream if stream is not None else torch.cuda.current_stream(queries.device)
+        capi.check(self._lib.roar_exact_knn_device(self._h, C.c_void_p(queries.data_ptr()), nq, queries.shape[1], int(k),
+                                                   C.c_void_p(ids.data_ptr()),
+                                                   C.c_void_p(dists.data_ptr()) if want_dists else None,
+                                                   C.c_void_p(st.cuda_stream)))
+        return ids, dists
 
     def Distances(self, queries, ids):
         """distance_->compare(base[id], query, dim) for explicit ids [nq, m] (distance.h:39-89,179-223)."""

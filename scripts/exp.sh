@@ -1,6 +1,3 @@
-echo "== torchrun nproc 1"
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>gpurun_out/tr.err | cut -c1-700; tail -3 gpurun_out/tr.err
-echo "== webvid"
-python bench.py --workload webvid --steps 5 --warmup 2 --cpu-seconds 5 2>gpurun_out/wv.err | cut -c1-2500; grep -E "bootstrap|L_pq=" gpurun_out/wv.err | tail -8
-echo "== sift"
-python bench.py --workload sift --steps 5 --warmup 2 --cpu-seconds 5 2>gpurun_out/sf.err | cut -c1-2500; grep -E "bootstrap|L_pq=" gpurun_out/sf.err | tail -8
+for L in 150 300 500 1000 1500; do for v in lds exact; do
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --L $L --visited $v 2>/dev/null | python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print('L',r['config']['L_pq'],r['config']['visited'],'recall',round(r['config']['recall_at_10'],4),'kernel_ms',round(r['roofline']['kernel_ms'],2),'frac',round(r['roofline']['frac'],3),'grid',r['roofline']['grid'],'lds',r['roofline']['lds_bytes'],'cmps',int(r['roofline']['lds_mode_cmps']))"
+done; done

@@ -397,3 +397,60 @@ def test_mid_scale_built_graph_many_queries(built_lib):
         idx.SaveProjectionGraph(p)
         ep2, off2, nbrs2 = oracle.graph_load(p)
         assert ep2 == ep and np.array_equal(off2, off) and np.array_equal(nbrs2, nbrs)
+
+
+@pytest.mark.parametrize("metric,d,k", [(1, 200, 10), (0, 128, 10), (1, 72, 100), (0, 512, 32)])
+def test_exact_knn_generator_matches_brute_force(metric, d, k, built_lib):
+    """ids of the MFMA brute-force kNN == numpy float64 brute force (where the k-th and
+    (k+1)-th distances are not within rounding), distances within 1e-4 relative of the oracle's."""
+    import torch
+
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, nq = 50_000, 300
+    rng = np.random.default_rng(d + k)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = mi.IndexBipartite(d, n, metric, None)
+    idx.SetBaseData(base)
+    ids, dists = idx.ExactKnnDevice(torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    ids = ids.cpu().numpy().view(np.uint32)
+    dists = dists.cpu().numpy()
+    b64, q64 = base.astype(np.float64), q.astype(np.float64)
+    dot = q64 @ b64.T
+    full = -dot if metric == 1 else (q64 ** 2).sum(1)[:, None] - 2 * dot + (b64 ** 2).sum(1)[None, :]
+    order = np.argsort(full, axis=1, kind="stable")[:, :k + 1]
+    want = order[:, :k]
+    scale = np.abs(np.take_along_axis(full, want, 1)).max(axis=1)
+    gap = np.take_along_axis(full, order[:, k:k + 1], 1)[:, 0] - np.take_along_axis(full, order[:, k - 1:k], 1)[:, 0]
+    clear = gap > 1e-5 * scale  # queries whose top-k set is unambiguous in f32
+    assert clear.mean() > 0.9
+    got_sets = np.sort(ids[clear], axis=1)
+    assert np.array_equal(got_sets, np.sort(want[clear], axis=1))
+    # distances: sorted ascending, and equal to the reference-order distance of the returned id
+    assert (np.diff(dists, axis=1) >= 0).all()
+    for qi in (0, 17, nq - 1):
+        ref = np.array([oracle.dist(metric, base[i], q[qi]) for i in ids[qi]], np.float32)
+        assert np.allclose(dists[qi], ref, rtol=1e-4, atol=1e-4 * scale[qi])
+
+
+def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
+    """Default policy: on-chip tag table below L_pq = 512, HBM epoch tags from there on; both give the
+    reference's results."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 5000, 128, 20
+    base, q, off, nbrs = _random_case(n, d, nq, 0, seed=21, maxdeg=40)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(9, off, nbrs)
+    assert idx.info("visited_mode") == 2
+    for L, want_mode in ((50, 1), (511, 1), (512, 0), (900, 0)):
+        r = idx.SearchRoarGraphBatch(q, K, L)
+        assert idx.info("last_visited_mode") == want_mode
+        o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
+        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
+        assert np.array_equal(r["hops"], o["hops"])

@@ -224,8 +224,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // AUTO: the on-chip tag table while it still leaves 8 waves per CU (L_pq < 512), HBM epoch tags
     // beyond (measured on T2I-10M: LDS 15.4 / 28.9 / 49.1 ms vs EXACT 19.3 / 33.3 / 50.7 ms at
     // L_pq = 150 / 300 / 500, but 250 vs 126 ms at L_pq = 1500)
-    const int mode = idx->visited_mode == ROAR_VISITED_AUTO ? (L < 512 ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
-                                                            : idx->visited_mode;
+    // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
+    const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;
+    const int mode = idx->visited_mode == ROAR_VISITED_AUTO
+                         ? ((L < 512 && lds_fits) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
+                         : idx->visited_mode;
     idx->last_mode = mode;
     // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
     uint32_t sets_log2 = 0;

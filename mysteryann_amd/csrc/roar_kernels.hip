@@ -129,13 +129,70 @@ __device__ __forceinline__ float row_distance(const float *__restrict__ rowp, co
     return IP ? -r : r;  // distance.h:223
 }
 
-// Score cid[0..m) against the query; ck[i] = key(distance, id).  16 rows per pass.
+// Tail of row_distance shared by the one-row and two-row forms: 16 -> 8 -> (8-float step) -> 4 -> hadd.
+template <bool IP>
+__device__ __forceinline__ float reduce_row(float4 acc, const float *__restrict__ rowp, const float *lq, uint32_t dim,
+                                            uint32_t done, int t) {
+    float4 s1;
+    s1.x = quad_xor2(acc.x) + acc.x;
+    s1.y = quad_xor2(acc.y) + acc.y;
+    s1.z = quad_xor2(acc.z) + acc.z;
+    s1.w = quad_xor2(acc.w) + acc.w;
+    if (dim & 8) {
+        const float4 *rt = reinterpret_cast<const float4 *>(rowp) + 4 * done + (t & 1);
+        const float4 *qt = reinterpret_cast<const float4 *>(lq) + 4 * done + (t & 1);
+        acc16<IP>(s1, *rt, *qt);
+    }
+    float a = quad_xor1(s1.x) + s1.x;
+    float b = quad_xor1(s1.y) + s1.y;
+    float c2 = quad_xor1(s1.z) + s1.z;
+    float d = quad_xor1(s1.w) + s1.w;
+    float r = (a + b) + (c2 + d);
+    return IP ? -r : r;
+}
+
+// Score cid[0..m) against the query; ck[i] = key(distance, id).  16 rows per pass; with a
+// compile-time row length two passes (32 rows) are in flight at once: every load of both rows is
+// issued before the first FMA, the query fragments are read from LDS once for the pair.
 template <bool IP, int NCH>
 __device__ __forceinline__ void score_candidates(const float *__restrict__ base, uint64_t ld, uint32_t dim,
                                                  const float *lq, const uint32_t *cid, u64 *ck, uint32_t m,
                                                  int lane) {
     const int t = lane & 3, g = lane >> 2;
-    for (uint32_t p0 = 0; p0 < m; p0 += 16) {
+    uint32_t p0 = 0;
+    if (NCH > 0) {
+        for (; p0 + 16 < m; p0 += 32) {
+            const uint32_t c0 = p0 + g, c1 = p0 + 16 + g;  // c0 < m always here
+            const bool has1 = c1 < m;
+            const uint32_t id0 = cid[c0];
+            const uint32_t id1 = has1 ? cid[c1] : id0;
+            const float *r0 = base + (u64)id0 * ld, *r1 = base + (u64)id1 * ld;
+            const float4 *row0 = reinterpret_cast<const float4 *>(r0) + t;
+            const float4 *row1 = reinterpret_cast<const float4 *>(r1) + t;
+            const float4 *q4 = reinterpret_cast<const float4 *>(lq) + t;
+            float4 x0[NCH > 0 ? NCH : 1], x1[NCH > 0 ? NCH : 1];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) x0[i] = row0[4 * i];
+            if (has1) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) x1[i] = row1[4 * i];
+            }
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 y = q4[4 * i];
+                acc16<IP>(a0, x0[i], y);
+                if (has1) acc16<IP>(a1, x1[i], y);
+            }
+            const float d0 = reduce_row<IP>(a0, r0, lq, dim, NCH, t);
+            if (t == 0) ck[c0] = make_key(d0, id0);
+            if (has1) {
+                const float d1 = reduce_row<IP>(a1, r1, lq, dim, NCH, t);
+                if (t == 0) ck[c1] = make_key(d1, id1);
+            }
+        }
+    }
+    for (; p0 < m; p0 += 16) {
         const uint32_t c = p0 + g;
         if (c < m) {  // whole 4-lane groups are active or idle together
             const uint32_t id = cid[c];
@@ -217,7 +274,7 @@ constexpr int VIS_EXACT = 0;
 constexpr int VIS_LDS = 1;
 
 template <int MODE, bool IP, int NCH>
-__global__ void __launch_bounds__(64, 4) roar_search_kernel(const RoarSearchParams p) {
+__global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);

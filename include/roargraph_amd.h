@@ -166,7 +166,9 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_AUTO (default AUTO)
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq; power of two)
- *   "max_grid"       cap on the number of resident waves launched (0 = no cap)
+ *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
+ *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query
+ *                    (latency form; auto picks it when the whole batch is resident that way)
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
  *   "row_stride", "last_grid", "last_lds_bytes", "last_vis_entries", "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;

@@ -86,6 +86,8 @@ struct roar_index {
     int waves_per_cu = 0;
     int vis_entries = 0;
     int max_grid = 0;
+    int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query
+    int last_mw = 0;
     // workspaces
     uint32_t *counters = nullptr;  // [0] dequeue counter, [1] short count
     uint8_t *tags = nullptr;
@@ -251,18 +253,34 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
     p.off_ck = off;
-    off += 8 * 64;
+    off += 8 * 128;
     p.off_cid = off;
-    off += 4 * 64;
+    off += 4 * 128;
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
     p.off_vis = off;
     off += 2 * entries;
+    p.off_ctrl = off;
+    off += 16;
     p.lds_bytes = off;
     if (p.lds_bytes > 160 * 1024) return fail(ROAR_ERR_ARG, "L_pq = %u needs %u bytes of LDS per query (max 163840)", L, off);
-    int occ = 0;
-    int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, idx->dim_pad, p.lds_bytes, &occ);
-    if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+    // kernel form: four waves per query when the whole batch is resident that way (latency form),
+    // one wave per query otherwise (throughput form)
+    int occ = 0, mw = 0;
+    if (idx->search_kernel != 1) {
+        int occ_mw = 0;
+        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 1, idx->dim_pad, p.lds_bytes, &occ_mw);
+        if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+        if (occ_mw >= 1 && (idx->search_kernel == 2 || nq <= (uint64_t)occ_mw * (uint64_t)idx->n_cus)) {
+            mw = 1;
+            occ = occ_mw;
+        }
+    }
+    if (!mw) {
+        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 0, idx->dim_pad, p.lds_bytes, &occ);
+        if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    idx->last_mw = mw;
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
@@ -711,7 +729,7 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, plan.grid, st);
+    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, idx->last_mw, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -905,6 +923,9 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "vis_entries") {
         if (value < 0 || (value & (value - 1))) return fail(ROAR_ERR_ARG, "vis_entries must be 0 or a power of two");
         idx->vis_entries = (int)value;
+    } else if (k == "search_kernel") {
+        if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1 or 2");
+        idx->search_kernel = (int)value;
     } else if (k == "max_grid") {
         if (value < 0) return fail(ROAR_ERR_ARG, "max_grid must be >= 0");
         idx->max_grid = (int)value;
@@ -929,6 +950,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
+    else if (k == "last_waves_per_query") *value = idx->last_mw ? 4 : 1;
     else if (k == "last_grid") *value = idx->last_grid;
     else if (k == "last_lds_bytes") *value = idx->last_lds;
     else if (k == "last_vis_entries") *value = idx->last_vis_entries;

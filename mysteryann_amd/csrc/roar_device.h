@@ -35,7 +35,7 @@ struct RoarSearchParams {
     uint64_t tag_stride;
     uint32_t *epochs;
     // LDS carve-up (byte offsets, all 16-byte aligned)
-    uint32_t off_pool, off_ck, off_cid, off_q, off_vis, lds_bytes;
+    uint32_t off_pool, off_ck, off_cid, off_q, off_vis, off_ctrl, lds_bytes;
 };
 
 struct RoarDistParams {
@@ -56,12 +56,14 @@ extern "C" {
 #endif
 // Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
 // visited_mode: 0 exact tags, 1 LDS table.  Returns a hipError_t value (0 = success).
-int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, uint32_t grid, void *stream);
+int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave, uint32_t grid,
+                       void *stream);
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
 // Max resident single-wave workgroups per CU for the search kernel variant at this LDS size.
-int roar_search_occupancy(int metric_ip, int visited_mode, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
+int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
+                          int *blocks_per_cu);
 #ifdef __cplusplus
 }
 #endif

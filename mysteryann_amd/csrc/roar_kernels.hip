@@ -273,6 +273,56 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
 constexpr int VIS_EXACT = 0;
 constexpr int VIS_LDS = 1;
 
+// visited test-and-set for one adjacency chunk (lane = one neighbour); returns "not visited before".
+template <int MODE>
+__device__ __forceinline__ bool visited_filter(bool isnbr, uint32_t nb, uint16_t *vis, uint32_t sets_mask,
+                                               uint32_t sets_log2, uint8_t *tags, uint32_t epoch) {
+    bool fresh;
+    if (MODE == VIS_LDS) {
+        // 4-way set of u16 tags; (set, tag) <-> id is a bijection, so a hit is never false.
+        // The table may forget (way overwritten): the node is then scored again and the
+        // duplicate key is dropped by the merge, results are unchanged.
+        const uint32_t set = nb & sets_mask;
+        const uint32_t tag = (nb >> sets_log2) + 1u;
+        const uint2 ww = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+        const uint32_t t0 = ww.x & 0xFFFFu, t1 = ww.x >> 16, t2 = ww.y & 0xFFFFu, t3 = ww.y >> 16;
+        const bool hit = (t0 == tag) | (t1 == tag) | (t2 == tag) | (t3 == tag);
+        fresh = isnbr && !hit;
+        // Insert.  Lanes of this instruction that share a set race for the same empty
+        // way, so a write into an empty way is verified on the next round and retried
+        // by the loser; a full set overwrites a victim way without verification (that is
+        // the only place the table forgets).
+        bool pending = fresh;
+        uint32_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
+        while (__ballot(pending)) {
+            if (pending) {
+                const bool present = (a0 == tag) | (a1 == tag) | (a2 == tag) | (a3 == tag);
+                const bool full = (a0 != 0) & (a1 != 0) & (a2 != 0) & (a3 != 0);
+                if (present) {
+                    pending = false;
+                } else {
+                    const uint32_t way = a0 == 0 ? 0u : a1 == 0 ? 1u : a2 == 0 ? 2u : a3 == 0 ? 3u : (tag & 3u);
+                    vis[4 * set + way] = (uint16_t)tag;
+                    if (full) pending = false;
+                }
+            }
+            wave_sync();
+            if (pending) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+                a0 = w2.x & 0xFFFFu, a1 = w2.x >> 16, a2 = w2.y & 0xFFFFu, a3 = w2.y >> 16;
+            }
+            wave_sync();
+        }
+    } else {  // visited_array[nbr] != tag ... = tag  (index_bipartite.cpp:2378,2385)
+        uint32_t tg = 0;
+        if (isnbr) tg = __builtin_nontemporal_load(tags + nb);
+        fresh = isnbr && tg != epoch;
+        if (fresh) __builtin_nontemporal_store((uint8_t)epoch, tags + nb);
+    }
+    return fresh;
+}
+
+
 template <int MODE, bool IP, int NCH>
 __global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -348,48 +398,7 @@ __global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchPara
                 const uint32_t w = w0 + (uint32_t)lane;
                 const bool isnbr = w >= 1 && w <= deg;
                 const uint32_t nb = isnbr ? word : 0u;
-                bool fresh;
-                if (MODE == VIS_LDS) {
-                    // 4-way set of u16 tags; (set, tag) <-> id is a bijection, so a hit is never false.
-                    // The table may forget (way overwritten): the node is then scored again and the
-                    // duplicate key is dropped by the merge, results are unchanged.
-                    const uint32_t set = nb & sets_mask;
-                    const uint32_t tag = (nb >> p.vis_sets_log2) + 1u;
-                    const uint2 ww = *reinterpret_cast<const uint2 *>(vis + 4 * set);
-                    const uint32_t t0 = ww.x & 0xFFFFu, t1 = ww.x >> 16, t2 = ww.y & 0xFFFFu, t3 = ww.y >> 16;
-                    const bool hit = (t0 == tag) | (t1 == tag) | (t2 == tag) | (t3 == tag);
-                    fresh = isnbr && !hit;
-                    // Insert.  Lanes of this instruction that share a set race for the same empty
-                    // way, so a write into an empty way is verified on the next round and retried
-                    // by the loser; a full set overwrites a victim way without verification (that is
-                    // the only place the table forgets).
-                    bool pending = fresh;
-                    uint32_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
-                    while (__ballot(pending)) {
-                        if (pending) {
-                            const bool present = (a0 == tag) | (a1 == tag) | (a2 == tag) | (a3 == tag);
-                            const bool full = (a0 != 0) & (a1 != 0) & (a2 != 0) & (a3 != 0);
-                            if (present) {
-                                pending = false;
-                            } else {
-                                const uint32_t way = a0 == 0 ? 0u : a1 == 0 ? 1u : a2 == 0 ? 2u : a3 == 0 ? 3u : (tag & 3u);
-                                vis[4 * set + way] = (uint16_t)tag;
-                                if (full) pending = false;
-                            }
-                        }
-                        wave_sync();
-                        if (pending) {
-                            const uint2 w2 = *reinterpret_cast<const uint2 *>(vis + 4 * set);
-                            a0 = w2.x & 0xFFFFu, a1 = w2.x >> 16, a2 = w2.y & 0xFFFFu, a3 = w2.y >> 16;
-                        }
-                        wave_sync();
-                    }
-                } else {  // visited_array[nbr] != tag ... = tag  (index_bipartite.cpp:2378,2385)
-                    uint32_t tg = 0;
-                    if (isnbr) tg = __builtin_nontemporal_load(tags + nb);
-                    fresh = isnbr && tg != epoch;
-                    if (fresh) __builtin_nontemporal_store((uint8_t)epoch, tags + nb);
-                }
+                const bool fresh = visited_filter<MODE>(isnbr, nb, vis, sets_mask, p.vis_sets_log2, tags, epoch);
                 const u64 fm = __ballot(fresh);
                 const uint32_t m = (uint32_t)__popcll(fm);
                 if (m == 0) continue;
@@ -423,6 +432,142 @@ __global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchPara
         wave_sync();
     }
     if (MODE == VIS_EXACT && lane == 0) p.epochs[blockIdx.x] = epoch;
+}
+
+// Latency form of the same search: one 256-thread workgroup (4 waves) per query.  Wave 0 runs the
+// sequential part exactly as roar_search_kernel does (select, adjacency, visited filter, merge); the
+// row gathers of a hop -- up to 128 candidates -- are spread over all four waves, 32 rows each with both
+// 16-row passes in flight, so a hop costs one adjacency round trip + one row round trip instead of
+// one per 16 rows.  Used when the whole batch fits the chip as 4-wave workgroups (small batches, the
+// per-query facade); results are the same by construction (same routines, same merge).
+template <int MODE, bool IP, int NCH>
+__global__ void __launch_bounds__(256) roar_search_kernel_mw(const RoarSearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck);
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
+    volatile uint32_t *ctrl = reinterpret_cast<volatile uint32_t *>(smem + p.off_ctrl);
+    const uint32_t L = p.L;
+    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    const uint32_t DONE = 0xFFFFFFFFu;
+    uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
+    uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
+
+    for (;;) {
+        if (threadIdx.x == 0) ctrl[0] = atomicAdd(p.counter, 1u);
+        __syncthreads();
+        const uint32_t q = ctrl[0];
+        if (q >= p.nq) break;
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 1024)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        if (MODE == VIS_LDS) {
+            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;
+            for (uint32_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            epoch++;
+            if (epoch == 256u) {
+                for (u64 i = (u64)threadIdx.x * 16; i < p.tag_stride; i += 4096)
+                    *reinterpret_cast<uint4 *>(tags + i) = make_uint4(0, 0, 0, 0);
+                __threadfence();
+                epoch = 1;
+            }
+        }
+        __syncthreads();
+        uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;  // live in wave 0
+        uint32_t wpos = 1, deg = 0, word0 = 0;
+        const uint32_t *arow = p.adj;
+        if (wid == 0) {
+            if (lane == 0) cid[0] = p.ep;
+            wave_sync();
+            score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, 1, lane);
+            wave_sync();
+            if (lane == 0) pool[0] = ck[0];
+            wave_sync();
+        }
+        for (;;) {
+            if (wid == 0) {
+                uint32_t m = 0;
+                bool done = false;
+                if (wpos > deg) {  // current node exhausted: expand the next one
+                    if (cur >= psize) {
+                        done = true;
+                    } else {
+                        const u64 e = pool[cur];
+                        const uint32_t v = (uint32_t)e >> 1;
+                        if (lane == 0) pool[cur] = e | 1ull;
+                        wave_sync();
+                        uint32_t found = psize;
+                        for (uint32_t c = cur + 1; c < psize; c += 64) {
+                            const uint32_t kidx = c + (uint32_t)lane;
+                            const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                            const u64 b = __ballot(unf);
+                            if (b) {
+                                found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                                break;
+                            }
+                        }
+                        cur = found;
+                        ++hops;
+                        arow = p.adj + (u64)v * p.adj_stride;
+                        word0 = arow[lane];
+                        deg = uni(word0);
+                        scanned += deg;
+                        wpos = 0;
+                    }
+                }
+                if (!done) {
+                    for (int c = 0; c < 2 && wpos <= deg; ++c, wpos += 64) {
+                        const uint32_t word = wpos ? arow[wpos + lane] : word0;
+                        const uint32_t w = wpos + (uint32_t)lane;
+                        const bool isnbr = w >= 1 && w <= deg;
+                        const uint32_t nb = isnbr ? word : 0u;
+                        const bool fresh = visited_filter<MODE>(isnbr, nb, vis, sets_mask, p.vis_sets_log2, tags, epoch);
+                        const u64 fm = __ballot(fresh);
+                        if (fresh) cid[m + lanes_below(fm)] = nb;
+                        m += (uint32_t)__popcll(fm);
+                    }
+                    cmps += m;
+                }
+                if (lane == 0) ctrl[1] = done ? DONE : m;
+            }
+            __syncthreads();
+            const uint32_t m = ctrl[1];
+            if (m == DONE) break;
+            const uint32_t lo = (uint32_t)wid * 32u;
+            if (lo < m)
+                score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid + lo, ck + lo, (m - lo < 32u) ? m - lo : 32u, lane);
+            __syncthreads();
+            if (wid == 0 && m) {
+                merge_candidates(pool, ck, m < 64u ? m : 64u, L, psize, cur, lane);
+                if (m > 64u) merge_candidates(pool, ck + 64, m - 64u, L, psize, cur, lane);
+            }
+        }
+        if (wid == 0) {
+            for (uint32_t i = lane; i < p.k; i += 64) {
+                uint32_t id = 0xFFFFFFFFu;
+                float d = __builtin_inff();
+                if (i < psize) {
+                    const u64 e = pool[i];
+                    id = (uint32_t)e >> 1;
+                    d = ord2f((uint32_t)(e >> 32));
+                }
+                p.out_ids[(u64)q * p.k + i] = id;
+                p.out_dists[(u64)q * p.k + i] = d;
+            }
+            if (lane == 0) {
+                if (p.out_cmps) p.out_cmps[q] = cmps;
+                if (p.out_hops) p.out_hops[q] = hops;
+                if (p.out_scanned) p.out_scanned[q] = scanned;
+                if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
 }
 
 // distance-only kernel: one wave per query, m explicit ids each (parity surface for A2/A3)
@@ -487,42 +632,45 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 }
 
 template <int MODE, bool IP>
-const void *pick_nch(uint32_t dim) {
+const void *pick_nch(uint32_t dim, int mw) {
     switch (dim >> 4) {
-        case 8: return (const void *)roar_search_kernel<MODE, IP, 8>;    // D = 128 (136)
-        case 12: return (const void *)roar_search_kernel<MODE, IP, 12>;  // D = 200 (192)
-        default: return (const void *)roar_search_kernel<MODE, IP, 0>;
+        case 8:  // D = 128 (136)
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 8> : (const void *)roar_search_kernel<MODE, IP, 8>;
+        case 12:  // D = 200 (192)
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 12> : (const void *)roar_search_kernel<MODE, IP, 12>;
+        default:
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 0> : (const void *)roar_search_kernel<MODE, IP, 0>;
     }
 }
 
-const void *pick_kernel(int metric_ip, int visited_mode, uint32_t dim) {
+const void *pick_kernel(int metric_ip, int visited_mode, uint32_t dim, int mw) {
     if (visited_mode == VIS_EXACT)
-        return metric_ip ? pick_nch<VIS_EXACT, true>(dim) : pick_nch<VIS_EXACT, false>(dim);
-    return metric_ip ? pick_nch<VIS_LDS, true>(dim) : pick_nch<VIS_LDS, false>(dim);
+        return metric_ip ? pick_nch<VIS_EXACT, true>(dim, mw) : pick_nch<VIS_EXACT, false>(dim, mw);
+    return metric_ip ? pick_nch<VIS_LDS, true>(dim, mw) : pick_nch<VIS_LDS, false>(dim, mw);
 }
 
 }  // namespace
 
-extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, uint32_t grid,
-                                  void *stream) {
-    const void *fn = pick_kernel(metric_ip, visited_mode, p->dim);
+extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave,
+                                  uint32_t grid, void *stream) {
+    const void *fn = pick_kernel(metric_ip, visited_mode, p->dim, multi_wave);
     if (p->lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     RoarSearchParams params = *p;
     void *args[] = {&params};
-    return (int)hipLaunchKernel(fn, dim3(grid), dim3(64), args, p->lds_bytes, (hipStream_t)stream);
+    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave ? 256 : 64), args, p->lds_bytes, (hipStream_t)stream);
 }
 
-extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, uint32_t dim, uint32_t lds_bytes,
+extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
                                      int *blocks_per_cu) {
-    const void *fn = pick_kernel(metric_ip, visited_mode, dim);
+    const void *fn = pick_kernel(metric_ip, visited_mode, dim, multi_wave);
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 64, lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave ? 256 : 64, lds_bytes);
 }
 
 extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {

@@ -454,3 +454,41 @@ def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
         o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
         assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
         assert np.array_equal(r["hops"], o["hops"])
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
+    """search_kernel = 2 (four waves per query) must return exactly what the throughput form and the
+    reference return: goldens, plus a random graph with degrees up to 200 (several 128-candidate
+    rounds per hop) and L_pq up to 700."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    for case in ("ip_200", "l2_128"):
+        exp = np.load(os.path.join(golden_dir, case + ".expected.npz"))
+        idx, q = _index(case, golden_dir, mode)
+        idx.set_option("search_kernel", 2)
+        for L in LS:
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            assert idx.info("last_waves_per_query") == 4
+            for key in ("ids", "dists", "hops", "scanned", "cmps"):
+                assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, L, key)
+        idx.close()
+    n, d, nq = 5000, 200, 24
+    base, q, off, nbrs = _random_case(n, d, nq, 1, seed=31, maxdeg=200)
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(2, off, nbrs)
+    idx.set_option("visited_mode", mode)
+    for kernel in (2, 1, 0):
+        idx.set_option("search_kernel", kernel)
+        for L in (10, 130, 700):
+            o = oracle.search_batch(base, off, nbrs, 2, q, K, L, 1)
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"]), (kernel, L)
+            assert np.array_equal(r["hops"], o["hops"]), (kernel, L)
+            if mode == 0:
+                assert np.array_equal(r["cmps"], o["cmps"]), (kernel, L)
+    idx.set_option("search_kernel", 0)
+    idx.SearchRoarGraphBatch(q, K, 50)
+    assert idx.info("last_waves_per_query") == 4  # 24 queries are resident as 4-wave workgroups

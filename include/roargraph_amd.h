@@ -121,6 +121,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *params);
  * `queries`: nq rows at `qstride_floats` stride holding at least `dim` floats each; for COSINE the
  * caller normalises queries first, as the harness does (tests/test_search_roargraph.cpp:167-172).
  * Host-buffer form: H2D of queries, launch, D2H of results.  Any of cmps/hops/scanned may be NULL.
+ * Safe to call from several host threads on one index (calls are serialised), like the reference's
+ * re-entrant SearchRoarGraph; the device-buffer form below is one host thread per index.
  * Returns ROAR_ERR_SHORT if some query ended with fewer than k results (their tail ids are
  * 0xFFFFFFFF); the other queries' results are still valid. */
 int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,

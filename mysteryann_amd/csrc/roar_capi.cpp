@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,10 @@ struct roar_index {
     uint64_t q_cap = 0;
     uint32_t *out_dev = nullptr;
     uint64_t out_cap = 0;
+    // SearchRoarGraph is re-entrant in the reference (called from num_threads OpenMP threads,
+    // tests/test_search_roargraph.cpp:203); the host-buffer entry points share staging buffers, the
+    // dequeue counter and the timing events, so concurrent callers are serialised here.
+    std::mutex mu;
     // last launch
     int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
 };
@@ -742,6 +747,7 @@ int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32
     if (!idx || !ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    std::lock_guard<std::mutex> guard(idx->mu);
     int e = use_device(idx);
     if (e) return e;
     // stage queries padded to dim_pad (data_align of the query block, tests/test_search_roargraph.cpp:131)
@@ -808,6 +814,7 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
     for (uint64_t i = 0; i < nq * m; ++i)
         if (ids[i] >= idx->n) return fail(ROAR_ERR_ARG, "id %u outside the base set", ids[i]);
+    std::lock_guard<std::mutex> guard(idx->mu);
     int e = use_device(idx);
     if (e) return e;
     float *q_dev = nullptr, *o_dev = nullptr;

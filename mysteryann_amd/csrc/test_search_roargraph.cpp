@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -31,6 +32,27 @@ static float ComputeRecall(uint32_t q_num, uint32_t k, uint32_t gt_dim, const ui
     return (float)total / (float)(k * q_num);
 }
 
+// Relative distance error of the returned neighbours against the ground-truth distances; the
+// reference defines it in tests/test_search_roargraph.cpp:38-62 (never called there) and prints it
+// from the bipartite driver (tests/test_search_bipartite.cpp:226-231).  IP results are negated
+// back to dot products, COSINE to 2 (1 - cos), as there.
+static double ComputeRderr(const float *gt_dist, uint32_t gt_dim, const float *res_d, uint32_t q_num, uint32_t k,
+                           efanna2e::Metric metric) {
+    double total = 0;
+    for (uint32_t i = 0; i < q_num; i++) {
+        double err = 0.0;
+        for (uint32_t j = 0; j < k; j++) {
+            double r = res_d[(size_t)i * k + j];
+            if (metric == efanna2e::INNER_PRODUCT) r = -r;
+            else if (metric == efanna2e::COSINE) r = 2.0 * (1.0 - (-r));
+            const double g = gt_dist[(size_t)i * gt_dim + j];
+            err += std::fabs(r - g) / g;
+        }
+        total += err / k;
+    }
+    return total / q_num;
+}
+
 static void usage() {
     std::cout << "Arguments:\n"
                  "  --data_type float            (only float is supported, as in the reference's driver)\n"
@@ -44,13 +66,15 @@ static void usage() {
                  "  --evaluation_save_path <csv>\n"
                  "  -T / --num_threads <n>       (per_query mode only)\n"
                  "  --per_query                  reference loop shape: one SearchRoarGraph call per query\n"
-                 "  --visited <exact|lds>        visited-set policy (default lds)\n"
+                 "  --visited <auto|exact|lds>   visited-set policy (default auto)\n"
+                 "  --rderr                      also print / save the relative distance error (7th CSV column)\n"
                  "  --device <ordinal>\n";
 }
 
 int main(int argc, char **argv) {
     std::string base_data_file, query_file, gt_file, projection_index_save_file, data_type = "float", dist;
-    std::string evaluation_save_path, visited = "lds";
+    std::string evaluation_save_path, visited = "auto";
+    bool want_rderr = false;
     std::vector<uint32_t> L_vec;
     uint32_t num_threads = omp_get_num_procs(), k = 1;
     int device = 0;
@@ -79,6 +103,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = std::stoi(next());
         else if (a == "--visited") visited = next();
         else if (a == "--per_query") per_query = true;
+        else if (a == "--rderr") want_rderr = true;
         else if (a == "--L_pq") {
             while (i + 1 < argc && argv[i + 1][0] != '-') L_vec.push_back((uint32_t)std::stoul(argv[++i]));
         } else {
@@ -140,7 +165,8 @@ int main(int argc, char **argv) {
             std::cout << "Normalizing query data" << std::endl;
             for (uint32_t i = 0; i < q_pts; i++) efanna2e::normalize<float>(aligned_query_data + (size_t)i * q_dim, q_dim);
         }
-        index.SetOption("visited_mode", visited == "exact" ? ROAR_VISITED_EXACT : ROAR_VISITED_LDS);
+        index.SetOption("visited_mode", visited == "exact" ? ROAR_VISITED_EXACT
+                                        : visited == "lds" ? ROAR_VISITED_LDS : ROAR_VISITED_AUTO);
         if (visited == "exact") index.InitVisitedListPool(num_threads);
 
         std::cout << "k: " << k << std::endl;
@@ -183,11 +209,19 @@ int main(int argc, char **argv) {
             for (size_t i = 0; i < q_pts; ++i) avg_cmps += cmps_vec[i], avg_hops += hops_vec[i];
             avg_cmps /= q_pts;
             avg_hops /= q_pts;
+            if (per_query)  // the per-query path fills res_dists[i]; flatten for the error metric
+                for (size_t i = 0; i < q_pts; ++i) std::copy(res_dists[i].begin(), res_dists[i].begin() + k, res_d.begin() + i * k);
+            double rderr = want_rderr ? ComputeRderr(gt_dists, gt_dim, res_d.data(), q_pts, k, dist_metric) : 0.0;
             std::cout << L_pq << "\t\t" << qps << "\t\t" << (float)avg_cmps << "\t\t" << (float)(diff_ms / q_pts) << "\t\t"
-                      << recall << "\t\t" << (float)avg_hops << std::endl;
-            if (evaluation_out.is_open())
+                      << recall << "\t\t" << (float)avg_hops;
+            if (want_rderr) std::cout << "\t\t" << rderr;
+            std::cout << std::endl;
+            if (evaluation_out.is_open()) {
                 evaluation_out << L_pq << "," << qps << "," << (float)avg_cmps << "," << (float)(diff_ms / q_pts) << ","
-                               << recall << "," << (float)avg_hops << std::endl;
+                               << recall << "," << (float)avg_hops;
+                if (want_rderr) evaluation_out << "," << rderr;
+                evaluation_out << std::endl;
+            }
         }
         free(aligned_query_data);
         delete[] gt_ids;

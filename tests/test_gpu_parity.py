@@ -492,3 +492,43 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
     idx.set_option("search_kernel", 0)
     idx.SearchRoarGraphBatch(q, K, 50)
     assert idx.info("last_waves_per_query") == 4  # 24 queries are resident as 4-wave workgroups
+
+
+def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
+    """BASELINE configs[0] shape through the file-based drop-in path: SIFT-like 128-d L2 set written as
+    .fbin / .ibin / graph index, searched by the C++ harness (mysteryann_amd/csrc/test_search_roargraph,
+    own counterpart of tests/test_search_roargraph.cpp) at L_pq = 100; its CSV row
+    L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops must carry the oracle's avg_cmps / recall / avg_hops."""
+    import subprocess
+
+    import oracle
+    from mysteryann_amd import fileio, synth
+    from tests.golden import small_builder as sb
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "mysteryann_amd", "csrc", "test_search_roargraph")
+    assert os.path.exists(exe), "harness not built (python __graft_entry__.py)"
+    n, nq, d = 6000, 200, 128
+    base, q, learn = synth.sift_numpy(n, nq, d, seed=4, n_learn=3000)
+    ep, adj = sb.build_roar_like(base, learn, 0, M_sq=24, M=12)
+    gt_i, gt_d = sb.exact_knn(q, base, 100, 0)
+    paths = {k: str(tmp_path / k) for k in ("base.fbin", "query.fbin", "gt.ibin", "roar.index", "eval.csv")}
+    fileio.write_fbin(paths["base.fbin"], base)
+    fileio.write_fbin(paths["query.fbin"], q)
+    fileio.write_gt(paths["gt.ibin"], gt_i, gt_d)
+    fileio.write_graph(paths["roar.index"], ep, adj)
+    for extra in ([], ["--visited", "exact"], ["--per_query", "-T", "4"]):
+        out = subprocess.run([exe, "--data_type", "float", "--dist", "l2", "--base_data_path", paths["base.fbin"],
+                              "--query_path", paths["query.fbin"], "--gt_path", paths["gt.ibin"],
+                              "--projection_index_save_path", paths["roar.index"], "--L_pq", "20", "100", "--k", "10",
+                              "--evaluation_save_path", paths["eval.csv"]] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr + out.stdout
+        rows = [r.split(",") for r in open(paths["eval.csv"]).read().strip().splitlines()]
+        assert [int(r[0]) for r in rows] == [20, 100]
+        off, nbrs = sb.to_csr(adj)
+        for r, L in zip(rows, (20, 100)):
+            o = oracle.search_batch(base, off, nbrs, ep, q, 10, L, 0)
+            assert abs(float(r[2]) - o["cmps"].mean()) < 2e-4 * o["cmps"].mean() + 1e-2, extra  # 6 printed digits
+            assert abs(float(r[5]) - o["hops"].mean()) < 2e-4 * o["hops"].mean() + 1e-3, extra
+            assert abs(float(r[4]) - oracle.recall(o["ids"], gt_i, 10)) < 1e-6

@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 One "step" = one pass of the hot path (the batched RoarGraph beam search, one kernel launch) over
-this rank's shard of the 10 000-query OOD batch, inputs already resident in HBM.  Workload
+this rank's 10 000-query OOD batch, inputs already resident in HBM.  Workload
 (config.workload "t2i-10M-ip"): synthetic base 10 M x 200-d f32 + 10 k out-of-distribution queries
 (mysteryann_amd/synth.py), inner-product metric, k = 10, index built in HBM by the
 bootstrap builder and replicated on every GPU.  Multi-GPU: the path shards by query with no

@@ -59,8 +59,11 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RoarError(ERR_DEVICE, "libroargraph_amd.so is not built (run __graft_entry__.build()); "
-                                    "there is no fallback implementation")
+        try:  # in-tree build (hipcc cross-compiles gfx950 without a GPU)
+            build_library()
+        except (OSError, subprocess.CalledProcessError) as e:
+            raise RoarError(ERR_DEVICE, f"libroargraph_amd.so is not built and cannot be built here ({e}); "
+                                        "there is no fallback implementation") from e
     # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and the system one has the
     # same SONAME, so whichever is mapped first serves both.  torch refuses to see the GPU on the
     # system runtime, therefore let torch map its copy before this library is loaded.

@@ -89,9 +89,12 @@ def main():
     ap.add_argument("--build-Mpj", type=int, default=24)
     ap.add_argument("--build-Llearn", type=int, default=128)
     ap.add_argument("--build-rounds", type=int, default=3)
-    ap.add_argument("--build-supply", type=int, default=0)
-    ap.add_argument("--build-supplyL", type=int, default=64)
+    ap.add_argument("--build-supply", type=int, default=12)
+    ap.add_argument("--build-supplyL", type=int, default=128)
     ap.add_argument("--build-Llast", type=int, default=0)
+    ap.add_argument("--build-C1", type=int, default=48, help="phase-1 candidates to prune from (0 = unpruned)")
+    ap.add_argument("--build-C3", type=int, default=48, help="supply candidates to prune from (0 = unpruned)")
+    ap.add_argument("--build-trim", type=int, nargs=2, default=[8, 0], metavar=("MIN_PROJ", "KEEP_BASE"))
     ap.add_argument("--max-L", type=int, default=2000)
     ap.add_argument("--exact-knn", type=int, default=0,
                     help="exact learn->base kNN lists (MFMA brute force) for the first N training queries")
@@ -151,7 +154,9 @@ def main():
                             L_build=args.build_L, learn=learn if n_learn else None, M_sq=args.build_Msq,
                             M_pj=args.build_Mpj, L_learn=args.build_Llearn, rounds=args.build_rounds,
                             phase1_l2=not args.build_phase1_ip, learn_knn=learn_knn, supply_k=args.build_supply,
-                            supply_L=args.build_supplyL, L_learn_last=args.build_Llast)
+                            supply_L=args.build_supplyL, L_learn_last=args.build_Llast,
+                            trim_min_proj=args.build_trim[0], trim_keep_base=args.build_trim[1],
+                            phase1_cand=args.build_C1, supply_cand=args.build_C3)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
@@ -282,9 +287,11 @@ def main():
                    else f"{args.workload}-shape-n{args.n}", "n_base": args.n,
                    "dim": args.dim, "metric": "l2" if metric == mi.L2 else "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
                    "recall_at_10": rec, "parallelism": f"query batches sharded over {world} GPU(s), index replicated, no collective",
-                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")], "index": f"bootstrap M={args.build_M} cap={args.build_basecap}/{args.build_maxdeg} "
+                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")], "index": f"skeleton M={args.build_M}/{args.build_C1} cap={args.build_basecap}/{args.build_maxdeg} "
                                                       f"L={args.build_L}; projection learn={n_learn} Msq={args.build_Msq} "
-                                                      f"Mpj={args.build_Mpj} L={args.build_Llearn} x{args.build_rounds}",
+                                                      f"Mpj={args.build_Mpj} L={args.build_Llearn} x{args.build_rounds}; supply "
+                                                      f"{args.build_supply}/{args.build_C3} L={args.build_supplyL}; trim "
+                                                      f"{args.build_trim[0]}/{args.build_trim[1]}",
                    "avg_degree": idx.info("nedges") / args.n, "build_seconds": build_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -110,6 +110,11 @@ typedef struct roar_build_params {
                             searching the finished graph with the node's own vector; 0 = skip */
     uint32_t supply_L;
     uint32_t L_learn_last; /* pool length of the last projection round (0 = L_learn) */
+    uint32_t phase1_cand;  /* > 0: phase 1 takes this many search results per node (<= 63) and occlusion-prunes
+                              them to M instead of linking the M nearest as they come */
+    uint32_t supply_cand;  /* > 0: phase 3 occlusion-prunes this many search results (<= 63) to supply_k */
+    uint32_t trim_min_proj;  /* after phase 2: rows with >= trim_min_proj projection edges keep only their */
+    uint32_t trim_keep_base; /* first trim_keep_base phase-1 edges (0 / 0 = keep everything) */
 } roar_build_params;
 int roar_build_graph(roar_index *idx, const roar_build_params *params);
 

@@ -125,32 +125,49 @@ __global__ void link_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_
     }
 }
 
-// projection step, one wave per training query.  res[t] = the query's (approximate) nearest base
-// points, nearest first.  pivot = res[0]; the other C-1 results are the candidates.  Following the
-// shape of the reference's projection (LinkProjection, src/index_bipartite.cpp:1059-1093, and the
-// occlusion rule of PruneBiSearchBaseGetBase, :1612-1694): candidates are ordered by their base-to-
-// base distance to the pivot, one is kept unless an already kept one is closer to it than the
-// pivot is, the list is back-filled with the nearest leftovers up to Mp, pivot -> kept edges are
-// written and each kept node gets the reverse edge.
-// Rows hold [bootstrap edges | projection edges]; base_deg[v] is where the projection part starts.
+// Occlusion-prune-and-link, one wave per list.  Two ways to name the node that receives the edges:
+//   pivot mode  (target_base < 0): list[0] is the target, list[1..C) are the candidates -- the projection
+//               step: list = a training query's nearest base points (LinkProjection,
+//               src/index_bipartite.cpp:1059-1093);
+//   target mode (target_base >= 0): list t belongs to node target_base + t and all C entries are
+//               candidates -- insertion of a new node from its own search results, and the connectivity
+//               supplement (:1188-1262) where a node is searched in the finished graph.
+// Rule (PruneBiSearchBaseGetBase, :1612-1694 / PruneProjectionBaseSearchCandidates, :1846-1940):
+// candidates are ordered by their base-to-base distance to the target; one is kept unless an already
+// kept one is closer to it than the target is; optionally back-filled with the nearest leftovers up to
+// Mp.  target -> kept edges are appended (row capacity cap_t), kept -> target edges too (cap_r).
+// In pivot mode a full target row refreshes one of its projection slots (rows are
+// [phase-1 edges | projection edges], base_deg[v] is where the projection part starts).
 template <bool IP>
-__global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg,
-                                                          const uint32_t *__restrict__ base_deg,
-                                                          const float *__restrict__ base, u64 ld, uint32_t dim,
-                                                          uint32_t count, const uint32_t *__restrict__ res,
-                                                          uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg,
-                                                          uint32_t salt) {
-    extern __shared__ __align__(16) float rows[];  // C x (dim + 1) floats, row 0 = pivot
+__global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r,
+                                                       const uint32_t *__restrict__ base_deg,
+                                                       const float *__restrict__ base, u64 ld, uint32_t dim,
+                                                       uint32_t count, const uint32_t *__restrict__ res,
+                                                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg,
+                                                       uint32_t salt, long long target_base, int skip_existing,
+                                                       int backfill, uint32_t skip_node) {
+    extern __shared__ __align__(16) float rows[];  // (ncand + 1) x (dim + 1) floats, row 0 = target
     const int lane = threadIdx.x;
     const uint32_t rs = dim + 1;
+    const bool tmode = target_base >= 0;
+    const uint32_t ncand = tmode ? C : C - 1;  // <= 63
     for (uint32_t t = blockIdx.x; t < count; t += gridDim.x) {
         const uint32_t *r = res + (u64)t * M;
-        uint32_t myid = (uint32_t)lane < C ? r[lane] : 0xFFFFFFFFu;
-        const uint32_t pivot = __builtin_amdgcn_readfirstlane((int)myid);
-        if (pivot == 0xFFFFFFFFu) continue;
-        if (lane > 0 && myid == pivot) myid = 0xFFFFFFFFu;
+        const uint32_t target = tmode ? (uint32_t)(target_base + t) : r[0];
+        if (target == 0xFFFFFFFFu || target == skip_node) continue;
+        uint32_t myid = 0xFFFFFFFFu;
+        if (lane == 0) myid = target;
+        else if ((uint32_t)lane <= ncand) myid = r[tmode ? lane - 1 : lane];
+        if (lane > 0 && myid == target) myid = 0xFFFFFFFFu;
+        uint32_t *trow = adj + (u64)target * S;
+        if (skip_existing && lane > 0 && myid != 0xFFFFFFFFu) {
+            const uint32_t td = trow[0] < cap_t ? trow[0] : cap_t;
+            bool have = false;
+            for (uint32_t q = 0; q < td; ++q) have |= trow[1 + q] == myid;
+            if (have) myid = 0xFFFFFFFFu;
+        }
         // gather the rows (coalesced: the wave walks one row at a time)
-        for (uint32_t c = 0; c < C; ++c) {
+        for (uint32_t c = 0; c <= ncand; ++c) {
             const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)myid, (int)c);
             if (id == 0xFFFFFFFFu) continue;
             const float *src = base + (u64)id * ld;
@@ -159,7 +176,6 @@ __global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // distance of every candidate to the pivot (lane j owns candidate j)
         auto dist_rows = [&](uint32_t a, uint32_t b) -> float {
             float s = 0.f;
             const float *x = rows + a * rs, *y = rows + b * rs;
@@ -169,13 +185,13 @@ __global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32
             }
             return IP ? -s : s;
         };
-        const bool cand = lane > 0 && (uint32_t)lane < C && myid != 0xFFFFFFFFu;
+        const bool cand = lane > 0 && (uint32_t)lane <= ncand && myid != 0xFFFFFFFFu;
         float dp = cand ? dist_rows((uint32_t)lane, 0) : __builtin_inff();
         const u64 key = cand ? (((u64)f2ord_b(dp) << 32) | myid) : ~0ull;
-        // order candidates by (distance to pivot, id); duplicates of an earlier lane drop out
+        // order candidates by (distance to target, id); duplicates of an earlier lane drop out
         uint32_t rank = 0;
         bool dupl = false;
-        for (uint32_t j = 1; j < C; ++j) {
+        for (uint32_t j = 1; j <= ncand; ++j) {
             const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)j);
             const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)j);
             const u64 kj = ((u64)khi << 32) | klo;
@@ -184,12 +200,11 @@ __global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32
             else if (kj == key && (int)j < lane) dupl = true;
         }
         const bool live = cand && !dupl;
-        // greedy occlusion in sorted order; `kept` lanes hold kept candidates
+        // greedy occlusion in sorted order (a duplicate has an equal key, so it never raised a rank;
+        // ranks of live lanes may have gaps, hence the loop over every possible rank)
         bool kept = false;
         uint32_t nkept = 0;
-        // note: ranks of live lanes are a permutation of 0..nlive-1 only if dropped duplicates are
-        // not counted; a duplicate has an equal key so it never increments anyone's rank.
-        for (uint32_t o = 0; o < C && nkept < Mp; ++o) {
+        for (uint32_t o = 0; o <= ncand && nkept < Mp; ++o) {
             const u64 who = __ballot(live && rank == o);
             if (!who) continue;
             const int c = __ffsll((long long)who) - 1;
@@ -201,42 +216,41 @@ __global__ void __launch_bounds__(64) project_prune_kernel(uint32_t *adj, uint32
                 nkept++;
             }
         }
-        // back-fill with the nearest leftovers (:1685-1691)
-        for (uint32_t o = 0; o < C && nkept < Mp; ++o) {
-            const u64 who = __ballot(live && !kept && rank == o);
-            if (!who) continue;
-            if (lane == __ffsll((long long)who) - 1) kept = true;
-            nkept++;
+        if (backfill) {  // :1685-1691
+            for (uint32_t o = 0; o <= ncand && nkept < Mp; ++o) {
+                const u64 who = __ballot(live && !kept && rank == o);
+                if (!who) continue;
+                if (lane == __ffsll((long long)who) - 1) kept = true;
+                nkept++;
+            }
         }
-        // write pivot -> kept (projection part of the row), and kept -> pivot
+        // target -> kept, kept -> target
         if (kept) {
-            uint32_t *prow = adj + (u64)pivot * S;
-            const uint32_t pd = prow[0] < max_deg ? prow[0] : max_deg;
+            const uint32_t pd = trow[0] < cap_t ? trow[0] : cap_t;
             bool have = false;
-            for (uint32_t q = 0; q < pd; ++q) have |= prow[1 + q] == myid;
+            for (uint32_t q = 0; q < pd; ++q) have |= trow[1 + q] == myid;
             if (!have) {
-                const uint32_t old = atomicAdd(&prow[0], 1u);
-                if (old < max_deg) {
-                    prow[1 + old] = myid;
+                const uint32_t old = atomicAdd(&trow[0], 1u);
+                if (old < cap_t) {
+                    trow[1 + old] = myid;
                     atomicAdd(&indeg[myid], 1u);
                 } else {
-                    atomicSub(&prow[0], 1u);
-                    const uint32_t b0 = base_deg[pivot] < max_deg ? base_deg[pivot] : max_deg;
-                    if (b0 < max_deg) {  // row full: refresh a projection slot
-                        const uint32_t slot = b0 + mix32(myid ^ salt ^ (t * 0x9E3779B9u)) % (max_deg - b0);
-                        prow[1 + slot] = myid;
+                    atomicSub(&trow[0], 1u);
+                    if (!tmode && base_deg) {  // row full: refresh a projection slot
+                        const uint32_t b0 = base_deg[target] < cap_t ? base_deg[target] : cap_t;
+                        if (b0 < cap_t) trow[1 + b0 + mix32(myid ^ salt ^ (t * 0x9E3779B9u)) % (cap_t - b0)] = myid;
                     }
                 }
             }
             uint32_t *urow = adj + (u64)myid * S;
-            const uint32_t ud = urow[0] < max_deg ? urow[0] : max_deg;
+            const uint32_t ud = urow[0] < cap_r ? urow[0] : cap_r;
             have = false;
-            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == pivot;
+            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == target;
             if (!have) {
                 const uint32_t old = atomicAdd(&urow[0], 1u);
-                if (old < max_deg) {
-                    urow[1 + old] = pivot;
-                    atomicAdd(&indeg[pivot], 1u);
+                if (old < cap_r) {
+                    urow[1 + old] = target;
+                    atomicAdd(&indeg[target], 1u);
                 } else {
                     atomicSub(&urow[0], 1u);
                 }
@@ -339,6 +353,21 @@ __global__ void dedupe_rows_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, 
     row[0] = out;
 }
 
+// optional trim: a row that received at least `min_proj` projection edges keeps only its first
+// `keep_base` phase-1 (base-to-base) edges; rows are [phase-1 edges | projection edges].
+__global__ void trim_base_edges_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, u64 n,
+                                       uint32_t min_proj, uint32_t keep_base) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t *row = adj + v * S;
+    const uint32_t deg = row[0] < max_deg ? row[0] : max_deg;
+    const uint32_t b = base_deg[v] < deg ? base_deg[v] : deg;
+    if (deg - b < min_proj || b <= keep_base) return;
+    uint32_t out = keep_base;
+    for (uint32_t j = b; j < deg; ++j) row[1 + out++] = row[1 + j];
+    row[0] = out;
+}
+
 __global__ void degree_stats_kernel(const uint32_t *adj, uint32_t S, u64 n, u64 *sum, uint32_t *maxd) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t d = v < n ? adj[v * S] : 0u;
@@ -363,6 +392,13 @@ extern "C" {
 int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream) {
     hipLaunchKernelGGL(dedupe_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
                        max_deg, (u64)n);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_trim(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, uint64_t n, uint32_t min_proj,
+                 uint32_t keep_base, void *stream) {
+    hipLaunchKernelGGL(trim_base_edges_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj,
+                       S, max_deg, base_deg, (u64)n, min_proj, keep_base);
     return (int)hipGetLastError();
 }
 
@@ -408,23 +444,28 @@ int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32
     return (int)hipGetLastError();
 }
 
-int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, const float *base,
-                    uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C,
-                    uint32_t Mp, uint32_t *indeg, uint32_t salt, void *stream) {
+int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
+                       const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
+                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
+                       int skip_existing, int backfill, uint32_t skip_node, void *stream) {
     if (count == 0) return 0;
-    const uint32_t lds = C * (dim + 1) * sizeof(float);
+    const uint32_t ncand = target_base >= 0 ? C : C - 1;
+    if (ncand > 63 || ncand == 0) return (int)hipErrorInvalidValue;
+    const uint32_t lds = (ncand + 1) * (dim + 1) * sizeof(float);
     const uint32_t grid = count < 8192u ? count : 8192u;
-    if (metric_ip) {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)project_prune_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(project_prune_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, max_deg,
-                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt);
-    } else {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)project_prune_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(project_prune_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, max_deg,
-                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt);
+    const void *fn = metric_ip ? (const void *)prune_link_kernel<true> : (const void *)prune_link_kernel<false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
     }
+    if (metric_ip)
+        hipLaunchKernelGGL(prune_link_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
+                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
+                           backfill, skip_node);
+    else
+        hipLaunchKernelGGL(prune_link_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
+                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
+                           backfill, skip_node);
     return (int)hipGetLastError();
 }
 

@@ -21,9 +21,10 @@ int roar_bk_entry_point(const float *base, uint64_t ld, uint32_t dim, uint64_t n
 int roar_bk_seed(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t M, void *stream);
 int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                  uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream);
-int roar_bk_project(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, const float *base,
-                    uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C,
-                    uint32_t Mp, uint32_t *indeg, uint32_t salt, void *stream);
+int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
+                       const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
+                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
+                       int skip_existing, int backfill, uint32_t skip_node, void *stream);
 int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                    uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream);
 int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
@@ -31,6 +32,8 @@ int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, u
 int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
 int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
                    uint32_t *orphans, void *stream);
+int roar_bk_trim(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, uint64_t n, uint32_t min_proj,
+                 uint32_t keep_base, void *stream);
 int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
 int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
                          void *stream);
@@ -595,7 +598,11 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     uint64_t max_batch = bp->max_batch ? bp->max_batch : (1u << 19);
     max_batch = std::min<uint64_t>(max_batch, std::max<uint64_t>(n, std::max<uint64_t>(n_learn, bp->n_knn)));
     const uint64_t cap = std::max<uint64_t>(max_batch, 1025);
-    const uint32_t K = std::max(std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u), bp->supply_k + 1);  // result row width
+    const uint32_t C1 = bp->phase1_cand, C3 = bp->supply_cand;
+    if (C1 > 63 || C3 > 63 || (C1 && C1 < M) || (C3 && C3 < bp->supply_k))
+        return fail(ROAR_ERR_ARG, "phase1_cand / supply_cand must be 0 or in [M | supply_k, 63]");
+    const uint32_t K = std::max(std::max(std::max(M, (n_learn || bp->learn_knn_dev) ? C : 0u), bp->supply_k + 1),
+                                std::max(C1, C3));  // result row width
     if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
     uint32_t *res_ids = nullptr, *indeg = nullptr, *scratch = nullptr, *base_deg = nullptr;
     float *res_d = nullptr, *sums = nullptr;
@@ -639,13 +646,26 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // phase 1: base-to-base links, rows capped at base_cap
     for (uint64_t a = seed; a < n;) {
         const uint64_t cnt = std::min<uint64_t>(std::min<uint64_t>(max_batch, a), n - a);
-        if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, M, L_build))) { cleanup(); return e; }
-        BK_TRY(roar_bk_link(idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
+        if (C1) {  // insert with occlusion pruning of the node's own search results
+            if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
+            BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
+                                      idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C1, C1, M, indeg, 0, (long long)a, 0, 1,
+                                      idx->ep, nullptr));
+        } else {
+            if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, M, L_build))) { cleanup(); return e; }
+            BK_TRY(roar_bk_link(idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
+        }
         a += cnt;
     }
     // seeds started with random links: give them real neighbours now that the graph exists
-    if ((e = search(idx->base, seed, idx->ld, M, L_build))) { cleanup(); return e; }
-    BK_TRY(roar_bk_link(idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
+    if (C1) {
+        if ((e = search(idx->base, seed, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
+        BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
+                                  idx->ip ? 1 : 0, seed, res_ids, C1, C1, M, indeg, 0, 0ll, 1, 1, 0xFFFFFFFFu, nullptr));
+    } else {
+        if ((e = search(idx->base, seed, idx->ld, M, L_build))) { cleanup(); return e; }
+        BK_TRY(roar_bk_link(idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
+    }
     idx->ip = saved_ip;
     BK_TRY(roar_bk_clamp(idx->adj, S, base_cap, n, nullptr));
     BK_TRY(roar_bk_snapshot_degree(idx->adj, S, max_degree, n, base_deg, nullptr));
@@ -655,8 +675,9 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (bp->learn_knn_dev && bp->n_knn) {
         for (uint64_t a = 0; a < bp->n_knn; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_knn - a);
-            BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
-                                   (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u, nullptr));
+            BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
+                                      idx->ip ? 1 : 0, (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u,
+                                      -1ll, 0, 1, 0xFFFFFFFFu, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }
@@ -668,8 +689,9 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                 cleanup();
                 return e;
             }
-            BK_TRY(roar_bk_project(idx->adj, S, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
-                                   (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), nullptr));
+            BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
+                                      idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), -1ll, 0,
+                                      1, 0xFFFFFFFFu, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }
@@ -679,12 +701,21 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         const uint32_t Ls = std::max<uint32_t>(bp->supply_L, Ks);
         for (uint64_t a = 0; a < n; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, n - a);
-            if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
-            BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
+            if (C3) {  // pruned supply edges: candidates = the node's search results not yet in its row
+                if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C3, std::max(Ls, C3)))) { cleanup(); return e; }
+                BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, nullptr, idx->base, idx->ld, idx->dim_pad,
+                                          idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C3, C3, Ks, indeg, 0, (long long)a, 1, 0,
+                                          0xFFFFFFFFu, nullptr));
+            } else {
+                if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
+                BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
+            }
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }
     BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+    // optional: drop phase-1 (skeleton) edges from rows that now hold enough projection / supply edges
+    if (bp->trim_min_proj) BK_TRY(roar_bk_trim(idx->adj, S, max_degree, base_deg, n, bp->trim_min_proj, bp->trim_keep_base, nullptr));
     for (uint32_t r = 0; r < 8; ++r) {
         BK_TRY(roar_bk_rescue(idx->adj, S, max_degree, n, idx->ep, r, indeg, scratch, nullptr));
         uint32_t orphans = 0;

@@ -4,6 +4,11 @@ traffic counters with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE c
 at 64 B -> x2; calibrated on this kernel's own access pattern by scripts/calib.sh)."""
 import csv, glob, json, os, sys
 
+
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 src, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(out, exist_ok=True)
@@ -17,7 +22,7 @@ def search_rows(path):
 
 
 # 1. kernel stats (top 12 rows, names shortened)
-stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0])))
+stats = list(csv.DictReader(open(newest(os.path.join(src, "trace/*/*_kernel_stats.csv")))))
 with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --L %d\n" % Lchosen)
     f.write("# (whole process: data generation, graph build, ground truth, L sweep is skipped with --L)\n")
@@ -28,12 +33,12 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 
 # 2. per-launch durations of the timed steps: the last 5+1+... launches of the IP search kernel at 10 000 queries
-trace = search_rows(glob.glob(os.path.join(src, "trace/*/*_kernel_trace.csv"))[0])
+trace = search_rows(newest(os.path.join(src, "trace/*/*_kernel_trace.csv")))
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace]
 timed = durs[-5:]
 # 3. PMC
 def pmc(name):
-    rows = search_rows(glob.glob(os.path.join(src, f"{name}/*/*_counter_collection.csv"))[0])
+    rows = search_rows(newest(os.path.join(src, f"{name}/*/*_counter_collection.csv")))
     return [float(r["Counter_Value"]) for r in rows][-5:], [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows][-5:]
 fetch, fd = pmc("pmc_fetch")
 write, wd = pmc("pmc_write")

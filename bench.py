@@ -88,19 +88,21 @@ def main():
     ap.add_argument("--build-Msq", type=int, default=48)
     ap.add_argument("--build-Mpj", type=int, default=24)
     ap.add_argument("--build-Llearn", type=int, default=128)
-    ap.add_argument("--build-rounds", type=int, default=3)
+    ap.add_argument("--build-rounds", type=int, default=2)
     ap.add_argument("--build-supply", type=int, default=12)
     ap.add_argument("--build-supplyL", type=int, default=128)
-    ap.add_argument("--build-Llast", type=int, default=0)
+    ap.add_argument("--build-Llast", type=int, default=256)
     ap.add_argument("--build-C1", type=int, default=48, help="phase-1 candidates to prune from (0 = unpruned)")
     ap.add_argument("--build-C3", type=int, default=48, help="supply candidates to prune from (0 = unpruned)")
+    ap.add_argument("--build-projmode", type=int, default=0)
+    ap.add_argument("--build-supplymode", type=int, default=0)
     ap.add_argument("--build-trim", type=int, nargs=2, default=[8, 0], metavar=("MIN_PROJ", "KEEP_BASE"))
     ap.add_argument("--max-L", type=int, default=2000)
     ap.add_argument("--exact-knn", type=int, default=0,
                     help="exact learn->base kNN lists (MFMA brute force) for the first N training queries")
     ap.add_argument("--torch-gt", action="store_true", help="ground truth by torch matmul+topk instead of the MFMA generator")
     ap.add_argument("--build-phase1-ip", action="store_true", help="phase 1 by the index metric instead of L2")
-    ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/4)")
+    ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
@@ -132,7 +134,7 @@ def main():
     from mysteryann_amd import synth
 
     t0 = time.time()
-    n_learn = args.learn if args.learn >= 0 else max(args.n // 4, 1000)
+    n_learn = args.learn if args.learn >= 0 else max(args.n // 2, 1000)
     gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch}[args.workload]
     base, queries, learn = gen(args.n, args.nq, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
                                query_seed=args.seed + 2 + 1000 * rank)
@@ -156,7 +158,8 @@ def main():
                             phase1_l2=not args.build_phase1_ip, learn_knn=learn_knn, supply_k=args.build_supply,
                             supply_L=args.build_supplyL, L_learn_last=args.build_Llast,
                             trim_min_proj=args.build_trim[0], trim_keep_base=args.build_trim[1],
-                            phase1_cand=args.build_C1, supply_cand=args.build_C3)
+                            phase1_cand=args.build_C1, supply_cand=args.build_C3, proj_mode=args.build_projmode,
+                            supply_mode=args.build_supplymode)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "

@@ -113,6 +113,9 @@ typedef struct roar_build_params {
     uint32_t phase1_cand;  /* > 0: phase 1 takes this many search results per node (<= 63) and occlusion-prunes
                               them to M instead of linking the M nearest as they come */
     uint32_t supply_cand;  /* > 0: phase 3 occlusion-prunes this many search results (<= 63) to supply_k */
+    uint32_t proj_mode;    /* projection pruning: 0 occlusion under the index metric (reference rule), 1 occlusion
+                              under L2, 2 no occlusion: the M_pj nearest to the training query */
+    uint32_t supply_mode;  /* same choices for the supply pass */
     uint32_t trim_min_proj;  /* after phase 2: rows with >= trim_min_proj projection edges keep only their */
     uint32_t trim_keep_base; /* first trim_keep_base phase-1 edges (0 / 0 = keep everything) */
 } roar_build_params;

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
                                                        uint32_t count, const uint32_t *__restrict__ res,
                                                        uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg,
                                                        uint32_t salt, long long target_base, int skip_existing,
-                                                       int backfill, uint32_t skip_node) {
+                                                       int backfill, uint32_t skip_node, int flags) {
     extern __shared__ __align__(16) float rows[];  // (ncand + 1) x (dim + 1) floats, row 0 = target
     const int lane = threadIdx.x;
     const uint32_t rs = dim + 1;
@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
         };
         const bool cand = lane > 0 && (uint32_t)lane <= ncand && myid != 0xFFFFFFFFu;
         float dp = cand ? dist_rows((uint32_t)lane, 0) : __builtin_inff();
-        const u64 key = cand ? (((u64)f2ord_b(dp) << 32) | myid) : ~0ull;
+        // flags bit 0: keep the list's own order (nearest to the training query first) instead of ordering
+        // by distance to the target; bit 1: no occlusion test (the first Mp live candidates are kept)
+        const u64 key = cand ? (((u64)((flags & 1) ? (uint32_t)lane : f2ord_b(dp)) << 32) | myid) : ~0ull;
         // order candidates by (distance to target, id); duplicates of an earlier lane drop out
         uint32_t rank = 0;
         bool dupl = false;
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
             const u64 kj = ((u64)khi << 32) | klo;
             if (kj == ~0ull || (int)j == lane) continue;
             if (kj < key) rank++;
-            else if (kj == key && (int)j < lane) dupl = true;
+            if ((uint32_t)kj == (uint32_t)key && (int)j < lane) dupl = true;  // same id earlier in the list
         }
         const bool live = cand && !dupl;
         // greedy occlusion in sorted order (a duplicate has an equal key, so it never raised a rank;
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
             const int c = __ffsll((long long)who) - 1;
             const float dc = __shfl(dp, c);
             bool occl = false;
-            if (kept) occl = dist_rows((uint32_t)lane, (uint32_t)c) < dc;
+            if (kept && !(flags & 2)) occl = dist_rows((uint32_t)lane, (uint32_t)c) < dc;
             if (__ballot(occl) == 0) {
                 if (lane == c) kept = true;
                 nkept++;
@@ -447,7 +449,7 @@ int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32
 int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
                        const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
                        uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
-                       int skip_existing, int backfill, uint32_t skip_node, void *stream) {
+                       int skip_existing, int backfill, uint32_t skip_node, int flags, void *stream) {
     if (count == 0) return 0;
     const uint32_t ncand = target_base >= 0 ? C : C - 1;
     if (ncand > 63 || ncand == 0) return (int)hipErrorInvalidValue;
@@ -461,11 +463,11 @@ int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r
     if (metric_ip)
         hipLaunchKernelGGL(prune_link_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
                            base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
-                           backfill, skip_node);
+                           backfill, skip_node, flags);
     else
         hipLaunchKernelGGL(prune_link_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
                            base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
-                           backfill, skip_node);
+                           backfill, skip_node, flags);
     return (int)hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32
 int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
                        const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
                        uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
-                       int skip_existing, int backfill, uint32_t skip_node, void *stream);
+                       int skip_existing, int backfill, uint32_t skip_node, int flags, void *stream);
 int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                    uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream);
 int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
@@ -244,11 +244,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
     if (mode == ROAR_VISITED_LDS) {
-        // auto: ~64 tags per pool slot, but never so large that fewer than 8 waves fit a CU (measured:
-        // 8192 entries is the optimum at L_pq = 75 on T2I-10M, 4096-8192 at L_pq = 240 on the SIFT
-        // shape; a smaller table only re-scores a few nodes, a larger one halves the occupancy)
-        uint32_t want = idx->vis_entries > 0 ? (uint32_t)idx->vis_entries : 64u * L;
-        if (idx->vis_entries <= 0) want = std::min(std::max(want, 2048u), L >= 512 ? 16384u : 8192u);
+        // auto: 8192 tags (16 KB) for every L_pq: it leaves 8 waves per CU and was the fastest table from
+        // L_pq = 20 to 75 on T2I-10M (e.g. L_pq = 60: 6.84 / 6.46 / 6.09 / 7.26 ms at 2048 / 4096 / 8192 /
+        // 16384 entries; a smaller table re-scores more nodes, a larger one halves the occupancy;
+        // 12 waves per CU, which the smaller tables would allow, is no faster than 8)
+        uint32_t want = idx->vis_entries > 0 ? (uint32_t)idx->vis_entries : 8192u;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
         while ((1u << sets_log2) < sets) sets_log2++;
@@ -650,7 +650,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
             if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
             BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
                                       idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C1, C1, M, indeg, 0, (long long)a, 0, 1,
-                                      idx->ep, nullptr));
+                                      idx->ep, 0, nullptr));
         } else {
             if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, M, L_build))) { cleanup(); return e; }
             BK_TRY(roar_bk_link(idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
@@ -661,7 +661,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (C1) {
         if ((e = search(idx->base, seed, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
         BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
-                                  idx->ip ? 1 : 0, seed, res_ids, C1, C1, M, indeg, 0, 0ll, 1, 1, 0xFFFFFFFFu, nullptr));
+                                  idx->ip ? 1 : 0, seed, res_ids, C1, C1, M, indeg, 0, 0ll, 1, 1, 0xFFFFFFFFu, 0, nullptr));
     } else {
         if ((e = search(idx->base, seed, idx->ld, M, L_build))) { cleanup(); return e; }
         BK_TRY(roar_bk_link(idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
@@ -669,6 +669,9 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     idx->ip = saved_ip;
     BK_TRY(roar_bk_clamp(idx->adj, S, base_cap, n, nullptr));
     BK_TRY(roar_bk_snapshot_degree(idx->adj, S, max_degree, n, base_deg, nullptr));
+    // projection pruning: 0 index metric (the reference's rule), 1 L2 geometry, 2 the list's own order, no occlusion
+    const int proj_ip = (bp->proj_mode == 1) ? 0 : (idx->ip ? 1 : 0);
+    const int proj_flags = (bp->proj_mode == 2) ? 3 : 0;
     // phase 2: projection of the training queries, `rounds` times over the improving graph
     // exact learn -> base kNN lists (the reference builder's input, LoadLearnBaseKNN,
     // src/index_bipartite.cpp:2622-2639) are projected first when the caller has them
@@ -676,8 +679,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         for (uint64_t a = 0; a < bp->n_knn; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_knn - a);
             BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
-                                      idx->ip ? 1 : 0, (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u,
-                                      -1ll, 0, 1, 0xFFFFFFFFu, nullptr));
+                                      proj_ip, (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u,
+                                      -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }
@@ -690,8 +693,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                 return e;
             }
             BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
-                                      idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), -1ll, 0,
-                                      1, 0xFFFFFFFFu, nullptr));
+                                      proj_ip, (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), -1ll, 0,
+                                      1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }
@@ -704,8 +707,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
             if (C3) {  // pruned supply edges: candidates = the node's search results not yet in its row
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C3, std::max(Ls, C3)))) { cleanup(); return e; }
                 BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, nullptr, idx->base, idx->ld, idx->dim_pad,
-                                          idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C3, C3, Ks, indeg, 0, (long long)a, 1, 0,
-                                          0xFFFFFFFFu, nullptr));
+                                          (bp->supply_mode == 1) ? 0 : (idx->ip ? 1 : 0), (uint32_t)cnt, res_ids, C3, C3, Ks, indeg, 0,
+                                          (long long)a, 1, 0, 0xFFFFFFFFu, (bp->supply_mode == 2) ? 3 : 0, nullptr));
             } else {
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
                 BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));

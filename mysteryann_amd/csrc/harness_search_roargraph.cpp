@@ -1,4 +1,4 @@
-// test_search_roargraph.cpp -- harness counterpart of the reference's
+// harness_search_roargraph.cpp (binary: test_search_roargraph) -- harness counterpart of the reference's
 // tests/test_search_roargraph.cpp (own code; same flags, same load sequence :118-173, same
 // per-L_pq loop :191-237, same stdout columns and CSV row `L_pq,qps,avg_cmps,mean_latency_ms,
 // recall,avg_hops`), written against include/roargraph_amd/efanna2e.h.

@@ -1,6 +1,6 @@
 """How do the host cores of the GPU box behave for the CPU baseline?  (thread scaling probe)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle
 print("nproc", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpuset.cpus.effective"):

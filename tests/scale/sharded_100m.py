@@ -11,7 +11,7 @@ kNN, MFMA generator), and -- the oracle of SURVEY 8(e) -- the merge of per-shard
 first --check queries must equal the GPU's merged ids and distances exactly.
 """
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

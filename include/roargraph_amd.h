@@ -116,6 +116,8 @@ typedef struct roar_build_params {
     uint32_t proj_mode;    /* projection pruning: 0 occlusion under the index metric (reference rule), 1 occlusion
                               under L2, 2 no occlusion: the M_pj nearest to the training query */
     uint32_t supply_mode;  /* same choices for the supply pass */
+    uint32_t no_skeleton;  /* 1: the reference's shape -- no phase 1; exact lists (learn_knn_dev) are projected with
+                              rows capped at M_pj, then the supply pass links every node, in growing batches */
     uint32_t trim_min_proj;  /* at the end: rows with >= trim_min_proj projection / supply edges keep only their */
     uint32_t trim_keep_base; /* first trim_keep_base phase-1 edges (0 / 0 = keep everything).  Applied only when
                                 phase 1 used another metric than the index (phase1_l2 on an IP / COSINE index) */

@@ -634,7 +634,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     HIP_TRY(hipMemcpy(&best, scratch, 8, hipMemcpyDeviceToHost));
     idx->ep = (uint32_t)(best & 0xFFFFFFFFu);
     const uint32_t seed = (uint32_t)std::min<uint64_t>(n, 1024);
-    BK_TRY(roar_bk_seed(idx->adj, S, seed, idx->ep, std::min<uint32_t>(M, seed - 1), nullptr));
+    if (!bp->no_skeleton) BK_TRY(roar_bk_seed(idx->adj, S, seed, idx->ep, std::min<uint32_t>(M, seed - 1), nullptr));
     idx->visited_mode = ROAR_VISITED_LDS;
     const bool saved_ip = idx->ip;
     auto search = [&](const float *q, uint64_t cnt, uint32_t qs, uint32_t k, uint32_t L) -> int {
@@ -643,8 +643,10 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // phase 1 may link base points by L2 even when the index metric is IP: base-to-base inner
     // products send every node to the few large-norm points and leave the rest without in-edges.
     if (bp->phase1_l2) idx->ip = false;
-    // phase 1: base-to-base links, rows capped at base_cap
-    for (uint64_t a = seed; a < n;) {
+    // phase 1: base-to-base links, rows capped at base_cap (skipped in the reference-shaped mode, which has
+    // no skeleton: connectivity then comes from the supply pass alone, as in LinkProjection)
+    const bool skeleton = !bp->no_skeleton;
+    for (uint64_t a = skeleton ? seed : n; a < n;) {
         const uint64_t cnt = std::min<uint64_t>(std::min<uint64_t>(max_batch, a), n - a);
         if (C1) {  // insert with occlusion pruning of the node's own search results
             if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
@@ -658,7 +660,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         a += cnt;
     }
     // seeds started with random links: give them real neighbours now that the graph exists
-    if (C1) {
+    if (!skeleton) {
+    } else if (C1) {
         if ((e = search(idx->base, seed, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
         BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
                                   idx->ip ? 1 : 0, seed, res_ids, C1, C1, M, indeg, 0, 0ll, 1, 1, 0xFFFFFFFFu, 0, nullptr));
@@ -672,13 +675,14 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // projection pruning: 0 index metric (the reference's rule), 1 L2 geometry, 2 the list's own order, no occlusion
     const int proj_ip = (bp->proj_mode == 1) ? 0 : (idx->ip ? 1 : 0);
     const int proj_flags = (bp->proj_mode == 2) ? 3 : 0;
+    const uint32_t proj_cap = bp->no_skeleton ? std::min(max_degree, Mp) : max_degree;
     // phase 2: projection of the training queries, `rounds` times over the improving graph
     // exact learn -> base kNN lists (the reference builder's input, LoadLearnBaseKNN,
     // src/index_bipartite.cpp:2622-2639) are projected first when the caller has them
     if (bp->learn_knn_dev && bp->n_knn) {
         for (uint64_t a = 0; a < bp->n_knn; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_knn - a);
-            BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
+            BK_TRY(roar_bk_prune_link(idx->adj, S, proj_cap, proj_cap, base_deg, idx->base, idx->ld, idx->dim_pad,
                                       proj_ip, (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u,
                                       -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
@@ -702,8 +706,11 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (bp->supply_k) {
         const uint32_t Ks = std::min<uint32_t>(bp->supply_k, K);
         const uint32_t Ls = std::max<uint32_t>(bp->supply_L, Ks);
-        for (uint64_t a = 0; a < n; a += max_batch) {
-            const uint64_t cnt = std::min<uint64_t>(max_batch, n - a);
+        for (uint64_t a = 0; a < n;) {
+            // without a skeleton the first nodes are linked one small batch at a time, each batch seeing
+            // the supply edges of the ones before it (the reference walks the nodes one by one)
+            const uint64_t cnt = std::min<uint64_t>(bp->no_skeleton ? std::min<uint64_t>(max_batch, std::max<uint64_t>(a / 2, 64))
+                                                                   : max_batch, n - a);
             if (C3) {  // pruned supply edges: candidates = the node's search results not yet in its row
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C3, std::max(Ls, C3)))) { cleanup(); return e; }
                 BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, nullptr, idx->base, idx->ld, idx->dim_pad,
@@ -713,6 +720,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
                 BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
             }
+            a += cnt;
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
     }

@@ -25,8 +25,8 @@ _libs = {}
 
 def build(force=False):
     """Compile liboracle.so (always possible) and _ref (only where /root/reference exists)."""
-    if force or not os.path.exists(_PORT) or os.path.getmtime(_PORT) < os.path.getmtime(
-            os.path.join(_HERE, "roar_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("roar_oracle.c", "roar_builder_oracle.c")]
+    if force or not os.path.exists(_PORT) or os.path.getmtime(_PORT) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, os.path.join(_HERE, "liboracle.so")],
                               stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/include/efanna2e") and (force or not os.path.exists(_REF)):
@@ -214,3 +214,35 @@ def recall(res, gt, k):
     l.oracle_recall.restype = C.c_float
     return float(l.oracle_recall(C.c_uint32(res.shape[0]), C.c_uint32(k), C.c_uint32(gt.shape[1]), _u32p(res),
                                  _u32p(gt)))
+
+
+def build_roargraph(base, learn_knn, metric, M_sq=100, M_pjbp=35, L_pjpq=500, flags=0):
+    """CPU restatement of the reference's BuildRoarGraph (oracle/roar_builder_oracle.c), single-threaded.
+    base [n, stride] f32, learn_knn [n_learn, K] u32 (nearest base ids per training query, nearest first).
+    -> ep, offsets u64[n+1], nbrs u32.  A yardstick for graph quality, not pinned to a reference build."""
+    base = np.ascontiguousarray(base, np.float32)
+    learn_knn = np.ascontiguousarray(learn_knn, np.uint32)
+    n, stride = base.shape
+    l = lib("port")
+    ep = C.c_uint32()
+    offsets = np.zeros(n + 1, np.uint64)
+    nbrs = np.zeros(n * 3 * M_pjbp + 16, np.uint32)
+    l.oracle_build_roargraph.restype = C.c_int
+    rc = l.oracle_build_roargraph(_f32p(base), C.c_uint32(n), C.c_uint64(stride), C.c_uint32(stride), C.c_int(metric),
+                                  _u32p(learn_knn), C.c_uint32(learn_knn.shape[0]), C.c_uint32(learn_knn.shape[1]),
+                                  C.c_uint32(M_sq), C.c_uint32(M_pjbp), C.c_uint32(L_pjpq), C.byref(ep), _u64p(offsets),
+                                  _u32p(nbrs), C.c_int(flags))
+    assert rc == 0
+    return ep.value, offsets, nbrs[:int(offsets[-1])]
+
+
+def prune_bisearch(base, metric, tgt, cand, M):
+    """PruneBiSearchBaseGetBase (src/index_bipartite.cpp:1612-1694) restated: kept ids, in order."""
+    base = np.ascontiguousarray(base, np.float32)
+    cand = np.ascontiguousarray(cand, np.uint32)
+    res = np.zeros(M + 4, np.uint32)
+    l = lib("port")
+    l.oracle_prune_bisearch.restype = C.c_uint32
+    nr = l.oracle_prune_bisearch(_f32p(base), C.c_uint64(base.shape[1]), C.c_uint32(base.shape[1]), C.c_int(metric),
+                                 C.c_uint32(tgt), _u32p(cand), C.c_uint32(len(cand)), C.c_uint32(M), _u32p(res))
+    return res[:nr].copy()

@@ -3,8 +3,8 @@
 Run in the build container only (needs /root/reference and oracle/_ref/libroar_ref.so, i.e.
 `make -C oracle`):   python tests/golden/make_golden.py
 
-Everything written is data: synthetic inputs (seeded numpy), a graph index built by
-tests/golden/small_builder.py in the reference's on-disk format, brute-force ground truth, and the
+Everything written is data: synthetic inputs (seeded numpy), a graph index built by the restated
+reference builder (oracle/roar_builder_oracle.c) in the reference's on-disk format, brute-force ground truth, and the
 outputs of oracle/_ref -- the reference's DistanceL2 / DistanceInnerProduct, NeighborPriorityQueue,
 VisitedListPool and util.h loaders compiled where they lie -- on those inputs.  No reference source
 text is stored.
@@ -41,11 +41,17 @@ CASES = {
 def make_case(name):
     gen, metric, n, nq, d = CASES[name]
     base, q, learn = gen(n, nq, d, seed=1234, n_learn=n)
-    ep, adj = sb.build_roar_like(base, learn, metric, M_sq=32, M=16)
+    # index: the CPU restatement of the reference's BuildRoarGraph (oracle/roar_builder_oracle.c) on exact
+    # learn->base lists with the canonical parameters M_sq=100 M_pjbp=35 L_pjpq=500 (run_roargraph_test.sh:9);
+    # COSINE builds on the normalised rows, as BuildRoarGraph does (src/index_bipartite.cpp:176-182)
+    bb = base if metric != oracle.METRIC_COSINE else (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    ll = learn if metric != oracle.METRIC_COSINE else (learn / np.linalg.norm(learn, axis=1, keepdims=True)).astype(np.float32)
+    knn, _ = sb.exact_knn(ll, bb, 100, metric)
+    ep, off, nbrs = oracle.build_roargraph(bb, knn, metric, 100, 35, 500)
     pre = os.path.join(HERE, name)
     fileio.write_fbin(pre + ".base.fbin", base)
     fileio.write_fbin(pre + ".query.fbin", q)
-    fileio.write_graph(pre + ".roar.index", ep, adj)
+    fileio.write_graph(pre + ".roar.index", ep, (off, nbrs))
     gt_ids, gt_d = sb.exact_knn(q, base, 100, metric)
     fileio.write_gt(pre + ".gt.ibin", gt_ids, gt_d)
     # the reference's loaders read the files back (load_meta / load_data / data_align)

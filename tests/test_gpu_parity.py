@@ -564,3 +564,65 @@ def test_builder_prune_kernel_matches_restated_prune_rule(metric, built_lib):
         got = set(int(x) for x in row)
         assert set(int(x) for x in want) <= got, (t, sorted(want), sorted(got))
         idx.close()
+
+
+def test_build_roargraph_reference_shape_against_restated_builder(tmp_path, built_lib):
+    """SURVEY 8(f) #1, first version: LoadLearnBaseKNN + BuildRoarGraph on the device against the CPU
+    restatement of the reference builder ON THE SAME DATA and the same exact learn->base lists, canonical
+    parameters (run_roargraph_test.sh:9).  The reference builder is nondeterministic, so parity is its
+    own notion: degree statistics and the recall-vs-cmps curve (here: recall within 0.015 at equal L_pq,
+    distance evaluations within 35 % -- the device graph is a little denser and a little more accurate), plus the file path: build CLI -> index file -> search CLI."""
+    import subprocess
+
+    import oracle
+    from mysteryann_amd import fileio, synth
+    from mysteryann_amd import index as mi
+    from tests.golden.small_builder import exact_knn
+
+    n, nq = 6000, 400
+    base, q, learn = synth.t2i_numpy(n, nq, n_learn=n, seed=77)
+    knn, _ = exact_knn(learn, base, 100, 1)
+    gt, gtd = exact_knn(q, base, 100, 1)
+    ep_r, off_r, nb_r = oracle.build_roargraph(base, knn, 1, 100, 35, 500)
+    deg_r = np.diff(off_r.astype(np.int64))
+    knn_path = str(tmp_path / "learn.base.knn.ibin")
+    fileio.write_knn(knn_path, knn)
+    idx = mi.IndexBipartite(200, n, mi.INNER_PRODUCT, None)
+    p = mi.Parameters()
+    p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 500)
+    idx.LoadLearnBaseKNN(knn_path)
+    idx.BuildRoarGraph(n, learn, n, base, p)
+    ep_g, off_g, nb_g = idx.GetProjectionGraph()
+    deg_g = np.diff(off_g.astype(np.int64))
+    assert ep_g == ep_r  # CalculateProjectionep
+    assert deg_g.max() <= 105 and deg_g.min() >= 1
+    assert 0.6 * deg_r.mean() <= deg_g.mean() <= 1.4 * deg_r.mean(), (deg_g.mean(), deg_r.mean())
+    for L in (30, 50, 100):
+        rr = oracle.search_batch(base, off_r, nb_r, ep_r, q, 10, L, 1, threads=4)
+        rg = oracle.search_batch(base, off_g, nb_g, ep_g, q, 10, L, 1, threads=4)
+        rec_r, rec_g = oracle.recall(rr["ids"], gt, 10), oracle.recall(rg["ids"], gt, 10)
+        assert rec_g >= rec_r - 0.015, (L, rec_g, rec_r)
+        assert rg["cmps"].mean() <= 1.35 * rr["cmps"].mean(), (L, rg["cmps"].mean(), rr["cmps"].mean())
+    # CLI pair on files: test_build_roargraph -> index -> test_search_roargraph
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = {k: str(tmp_path / k) for k in ("base.fbin", "learn.fbin", "query.fbin", "gt.ibin", "built.index", "eval.csv")}
+    fileio.write_fbin(paths["base.fbin"], base)
+    fileio.write_fbin(paths["learn.fbin"], learn)
+    fileio.write_fbin(paths["query.fbin"], q)
+    # ground-truth files carry plain inner products for --dist ip (ComputeRderr negates the search's
+    # distances before comparing, tests/test_search_roargraph.cpp:47-50)
+    fileio.write_gt(paths["gt.ibin"], gt, -gtd)
+    b = subprocess.run([os.path.join(root, "mysteryann_amd", "csrc", "test_build_roargraph"), "--data_type", "float",
+                        "--dist", "ip", "--base_data_path", paths["base.fbin"], "--sampled_query_data_path",
+                        paths["learn.fbin"], "--projection_index_save_path", paths["built.index"],
+                        "--learn_base_nn_path", knn_path, "--M_sq", "100", "--M_pjbp", "35", "--L_pjpq", "500", "-T", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr + b.stdout
+    s = subprocess.run([os.path.join(root, "mysteryann_amd", "csrc", "test_search_roargraph"), "--data_type", "float",
+                        "--dist", "ip", "--base_data_path", paths["base.fbin"], "--query_path", paths["query.fbin"],
+                        "--gt_path", paths["gt.ibin"], "--projection_index_save_path", paths["built.index"], "--L_pq", "50",
+                        "--k", "10", "--evaluation_save_path", paths["eval.csv"], "--rderr"],
+                       capture_output=True, text=True, timeout=600)
+    assert s.returncode == 0, s.stderr + s.stdout
+    row = open(paths["eval.csv"]).read().strip().split(",")
+    assert int(row[0]) == 50 and float(row[4]) > 0.97 and len(row) == 7 and abs(float(row[6])) < 0.05

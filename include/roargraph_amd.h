@@ -183,6 +183,10 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
 int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                           uint32_t *ids_dev, float *dists_dev, void *hip_stream);
 
+/* Host-buffer form of the same (queries: nq rows of `dim` valid floats; ids [nq][k], dists [nq][k] or NULL). */
+int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids,
+                   float *dists);
+
 /* ---- top-k merge for the index-sharded configuration ------------------------------------------
  * Not in the reference (new capability): merge `nshards` per-shard sorted top-k lists
  * per query by (distance, id) into a global top-k.  Device buffers laid out [shard][nq][k]. */

@@ -256,6 +256,10 @@ class IndexBipartite {
                                 nullptr));
     }
 
+    // exact kNN of `queries` among the loaded base rows (the producer of ground-truth / learn-base kNN files)
+    void ExactKnn(const float *queries, size_t nq, size_t k, unsigned *ids, float *dists) {
+        check(roar_exact_knn(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, ids, dists));
+    }
     void SetOption(const char *key, int64_t v) { check(roar_set_option(handle(), key, v)); }
     int64_t Info(const char *key) {
         int64_t v = 0;

@@ -20,7 +20,7 @@ SYMBOLS = [
     "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
     "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
     "roar_get_graph_csr", "roar_build_graph", "roar_build_roargraph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
-    "roar_exact_knn_device",
+    "roar_exact_knn_device", "roar_exact_knn",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
 ]
 
@@ -93,6 +93,7 @@ def lib():
                                            vp, vp]
     l.roar_distances.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, C.c_uint32, fp]
     l.roar_exact_knn_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp]
+    l.roar_exact_knn.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, u32p, fp]
     l.roar_merge_topk_device.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp]
     l.roar_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]

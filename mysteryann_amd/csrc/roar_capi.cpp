@@ -991,6 +991,39 @@ int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq
     return ROAR_OK;
 }
 
+int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids,
+                   float *dists) {
+    if (!idx || !queries || !ids) return fail(ROAR_ERR_ARG, "bad kNN arguments");
+    if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    if (nq == 0) return ROAR_OK;
+    int e = use_device(idx);
+    if (e) return e;
+    const uint64_t chunk = std::min<uint64_t>(nq, 1u << 18);
+    float *q_dev = nullptr, *d_dev = nullptr;
+    uint32_t *i_dev = nullptr;
+    std::vector<float> buf((size_t)chunk * idx->dim_pad);
+    HIP_TRY(hipMalloc((void **)&q_dev, buf.size() * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&i_dev, (size_t)chunk * k * 4));
+    HIP_TRY(hipMalloc((void **)&d_dev, (size_t)chunk * k * 4));
+    auto cleanup = [&]() { (void)hipFree(q_dev); (void)hipFree(i_dev); (void)hipFree(d_dev); };
+    for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const uint64_t cnt = std::min<uint64_t>(chunk, nq - q0);
+        std::fill(buf.begin(), buf.begin() + cnt * idx->dim_pad, 0.0f);
+        for (uint64_t i = 0; i < cnt; ++i)
+            memcpy(buf.data() + i * idx->dim_pad, queries + (q0 + i) * qstride_floats, idx->dim * sizeof(float));
+        hipError_t he = hipMemcpy(q_dev, buf.data(), (size_t)cnt * idx->dim_pad * sizeof(float), hipMemcpyHostToDevice);
+        if (he == hipSuccess) {
+            e = roar_exact_knn_device(idx, q_dev, cnt, idx->dim_pad, k, i_dev, d_dev, nullptr);
+            if (e) { cleanup(); return e; }
+            he = hipMemcpy(ids + q0 * k, i_dev, (size_t)cnt * k * 4, hipMemcpyDeviceToHost);
+        }
+        if (he == hipSuccess && dists) he = hipMemcpy(dists + q0 * k, d_dev, (size_t)cnt * k * 4, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) { cleanup(); return fail(ROAR_ERR_DEVICE, "exact kNN copy failed: %s", hipGetErrorString(he)); }
+    }
+    cleanup();
+    return ROAR_OK;
+}
+
 int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
                            const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream) {
     if (nshards == 0 || nshards > 32 || k == 0) return fail(ROAR_ERR_ARG, "merge needs 1..32 shards and k > 0");

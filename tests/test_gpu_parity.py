@@ -626,3 +626,46 @@ def test_build_roargraph_reference_shape_against_restated_builder(tmp_path, buil
     assert s.returncode == 0, s.stderr + s.stdout
     row = open(paths["eval.csv"]).read().strip().split(",")
     assert int(row[0]) == 50 and float(row[4]) > 0.97 and len(row) == 7 and abs(float(row[6])) < 0.05
+
+
+def test_cli_pipeline_from_fbin_files_only(tmp_path, built_lib):
+    """The whole reference workflow on files, CLIs only: compute_knn (learn->base lists, ground truth with
+    distances) -> test_build_roargraph -> test_search_roargraph (run_roargraph_test.sh,
+    run_roargraph_search_test.sh).  Cosine metric, ragged dimension (100 -> padded 104)."""
+    import subprocess
+
+    from mysteryann_amd import fileio, synth
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "mysteryann_amd", "csrc")
+    n, nq, d = 5000, 300, 100
+    base, q, learn = synth.t2i_numpy(n, nq, d, seed=5, n_learn=n)
+    P = {k: str(tmp_path / k) for k in ("base.fbin", "learn.fbin", "query.fbin", "knn.ibin", "gt.ibin", "roar.index", "eval.csv")}
+    fileio.write_fbin(P["base.fbin"], base)
+    fileio.write_fbin(P["learn.fbin"], learn)
+    fileio.write_fbin(P["query.fbin"], q)
+
+    def run(*cmd):
+        r = subprocess.run(list(cmd), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        return r.stdout
+
+    run(os.path.join(csrc, "compute_knn"), "--dist", "cosine", "--base_data_path", P["base.fbin"], "--query_path",
+        P["learn.fbin"], "--out_path", P["knn.ibin"], "--K", "100")
+    run(os.path.join(csrc, "compute_knn"), "--dist", "cosine", "--base_data_path", P["base.fbin"], "--query_path",
+        P["query.fbin"], "--out_path", P["gt.ibin"], "--K", "100", "--with_dists")
+    gt_ids, gt_d = fileio.read_gt(P["gt.ibin"])
+    bn = base / np.linalg.norm(base, axis=1, keepdims=True)
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    want = np.argsort(-(qn.astype(np.float64) @ bn.astype(np.float64).T), axis=1, kind="stable")[:, :10]
+    assert (np.sort(gt_ids[:, :10].astype(np.int64), 1) == np.sort(want, 1)).mean() > 0.995
+    assert (np.diff(gt_d, axis=1) <= 1e-6).all()  # plain cosines, best first
+    run(os.path.join(csrc, "test_build_roargraph"), "--data_type", "float", "--dist", "cosine", "--base_data_path",
+        P["base.fbin"], "--sampled_query_data_path", P["learn.fbin"], "--projection_index_save_path", P["roar.index"],
+        "--learn_base_nn_path", P["knn.ibin"], "--M_sq", "100", "--M_pjbp", "35", "--L_pjpq", "500")
+    run(os.path.join(csrc, "test_search_roargraph"), "--data_type", "float", "--dist", "cosine", "--base_data_path",
+        P["base.fbin"], "--query_path", P["query.fbin"], "--gt_path", P["gt.ibin"], "--projection_index_save_path",
+        P["roar.index"], "--L_pq", "10", "50", "--k", "10", "--evaluation_save_path", P["eval.csv"])
+    rows = [r.split(",") for r in open(P["eval.csv"]).read().strip().splitlines()]
+    assert [int(r[0]) for r in rows] == [10, 50]
+    assert float(rows[1][4]) > 0.97 and float(rows[1][4]) >= float(rows[0][4])

@@ -163,6 +163,43 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
                              uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
                              void *hip_stream);
 
+/* ---- bipartite two-hop variant (the paper's ablation baseline) -------------------
+ * Graph over base nodes [0, n) and training-query nodes [n, n_total); rows of base nodes hold
+ * training-query nodes and the reverse.  On-disk format of IndexBipartite::Save / Load
+ * (src/index_bipartite.cpp:2045-2071): u32 npts; npts x {u32 deg; u32 nbr[deg]} (no entry-point word). */
+int roar_load_bipartite_file(roar_index *idx, const char *path); /* IndexBipartite::Load  cpp:2060-2071 */
+int roar_save_bipartite_file(roar_index *idx, const char *path); /* IndexBipartite::Save  cpp:2045-2058 */
+int roar_set_bipartite_csr(roar_index *idx, uint64_t n_total, const uint64_t *offsets, const uint32_t *nbrs);
+/* two-phase like roar_get_graph_csr: offsets/nbrs may be NULL to size the buffers first */
+int roar_get_bipartite_csr(roar_index *idx, uint64_t *n_total, uint64_t *nedges, uint64_t *offsets, uint32_t *nbrs);
+
+/* BuildBipartite -> qbaseNNbipartite  src/index_bipartite.cpp:42-141, 235-280 (driver
+ * tests/test_only_build_bipartite.cpp:100-135): from the learn->base kNN lists (host, [n_learn][K], nearest
+ * first) keep min(K, M_pjbp) ids per training query; the nearest is its target and gains the edge
+ * target -> n + sq, the others form the row of node n + sq.  Target rows are filled in ascending sq
+ * (the reference's order depends on its OpenMP lock order; the search result does not depend on it). */
+int roar_build_bipartite(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_pjbp);
+
+/* Entry points.  The reference draws 10 uniform base ids per query from std::random_device
+ * (src/index_bipartite.cpp:287-294), so two runs of it differ; here the ids are an argument
+ * ([nq][n_init], 1 <= n_init <= 64) and this helper is the counter-based generator the host API uses
+ * when the caller passes NULL (seed = option "bipartite_seed", advanced after every such call). */
+int roar_bipartite_entry_ids(uint64_t seed, uint64_t nq, uint32_t n_init, uint64_t n_base, uint32_t *out);
+
+/* IndexBipartite::SearchBipartiteGraph  src/index_bipartite.cpp:282-356 under the harness loop
+ * tests/test_search_bipartite.cpp:194-201, batched.  Every entry point is scored, inserted and marked
+ * visited (not counted in cmps); an expansion scores the not-yet-visited base nodes two hops away
+ * (first occurrence wins); hops counts expansions, including those of nodes with an empty row.
+ * Errors as roar_search_batch ("not enough results: x, expected: k" -> ROAR_ERR_SHORT). */
+int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats,
+                                uint32_t k, uint32_t L_pq, const uint32_t *init_ids, uint32_t n_init, uint32_t *ids,
+                                float *dists, uint32_t *cmps, uint32_t *hops);
+int roar_search_bipartite_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq,
+                                       uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
+                                       const uint32_t *init_ids_dev, uint32_t n_init, uint32_t *ids_dev,
+                                       float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev,
+                                       uint32_t *scanned_dev, uint32_t *short_count_dev, void *hip_stream);
+
 /* ---- distance kernels alone -----------------------------------------------------------------
  * DistanceL2::compare / DistanceInnerProduct::compare  include/efanna2e/distance.h:39-89,179-223.
  * out[q * m + j] = distance(base[ids[q * m + j]], queries[q]) with the index's metric, computed
@@ -202,7 +239,9 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query
  *                    (latency form; auto picks it when the whole batch is resident that way)
+ *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
+ *   "bipartite_nodes", "bipartite_edges",
  *   "row_stride", "last_grid", "last_lds_bytes", "last_vis_entries", "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */

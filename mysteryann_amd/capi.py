@@ -22,6 +22,9 @@ SYMBOLS = [
     "roar_get_graph_csr", "roar_build_graph", "roar_build_roargraph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
     "roar_exact_knn_device", "roar_exact_knn",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
+    "roar_load_bipartite_file", "roar_save_bipartite_file", "roar_set_bipartite_csr", "roar_get_bipartite_csr",
+    "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
+    "roar_search_bipartite_batch_device",
 ]
 
 
@@ -98,6 +101,16 @@ def lib():
     l.roar_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     l.roar_init_visited_pool.argtypes = [vp, C.c_uint32]
+    l.roar_load_bipartite_file.argtypes = [vp, C.c_char_p]
+    l.roar_save_bipartite_file.argtypes = [vp, C.c_char_p]
+    l.roar_set_bipartite_csr.argtypes = [vp, C.c_uint64, u64p, u32p]
+    l.roar_get_bipartite_csr.argtypes = [vp, u64p, u64p, u64p, u32p]
+    l.roar_build_bipartite.argtypes = [vp, u32p, C.c_uint64, C.c_uint32, C.c_uint32]
+    l.roar_bipartite_entry_ids.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, u32p]
+    l.roar_search_bipartite_batch.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32,
+                                              u32p, fp, u32p, u32p]
+    l.roar_search_bipartite_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                                     C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     for s in SYMBOLS:
         if s not in ("roar_destroy", "roar_last_error"):
             getattr(l, s).restype = C.c_int

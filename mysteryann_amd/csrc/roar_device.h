@@ -36,6 +36,13 @@ struct RoarSearchParams {
     uint32_t *epochs;
     // LDS carve-up (byte offsets, all 16-byte aligned)
     uint32_t off_pool, off_ck, off_cid, off_q, off_vis, off_ctrl, lds_bytes;
+    // bipartite two-hop walk only (roar_bipartite_kernel): CSR over base + training-query nodes,
+    // explicit entry points [nq][n_init], 768 B of LDS at off_bp
+    const uint64_t *bp_off;
+    const uint32_t *bp_nbrs;
+    const uint32_t *init_ids;
+    uint32_t n_init;
+    uint32_t off_bp;
 };
 
 struct RoarDistParams {
@@ -55,7 +62,8 @@ struct RoarDistParams {
 extern "C" {
 #endif
 // Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
-// visited_mode: 0 exact tags, 1 LDS table.  Returns a hipError_t value (0 = success).
+// visited_mode: 0 exact tags, 1 LDS table.  multi_wave: 0 one wave per query, 1 four waves per query,
+// 2 bipartite two-hop walk (one wave per query).  Returns a hipError_t value (0 = success).
 int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave, uint32_t grid,
                        void *stream);
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);

@@ -570,6 +570,180 @@ __global__ void __launch_bounds__(256) roar_search_kernel_mw(const RoarSearchPar
     if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
 }
 
+// SearchBipartiteGraph (src/index_bipartite.cpp:282-356), the two-hop walk over the bipartite graph
+// (base node -> training-query nodes -> base nodes).  Same wave-per-query machinery as above; what
+// differs from SearchRoarGraph is kept as the reference has it:
+//   * n_init explicit entry points, every one scored, inserted and marked visited (:304-316; the
+//     reference draws them from std::random_device, here the caller passes them so a run can be replayed);
+//     they are not counted in cmps;
+//   * a hop with an empty row still counts (:324-327);
+//   * candidates of a hop = rows of the hop's query nodes, first occurrence wins (:330-334).
+// The rows are CSR (a base node's row is as long as the number of training queries it is nearest to,
+// which is unbounded).  64 query nodes of a hop are handled together: their row extents are prefix-
+// summed, the flattened candidate range is walked 64 entries at a time, survivors of the visited filter
+// are packed in LDS and scored 64 rows at a time.  Within a hop the order of the inserts cannot change
+// the pool (top-L of a set, duplicates dropped), so packing across rows is exact.
+template <int MODE, bool IP, int NCH>
+__global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck);
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
+    u64 *rstart = reinterpret_cast<u64 *>(smem + p.off_bp);              // [64] first word of each query node's row
+    uint32_t *rpre = reinterpret_cast<uint32_t *>(smem + p.off_bp + 512);  // [64] exclusive prefix of the row lengths
+    const uint32_t L = p.L;
+    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
+    uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
+
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(p.counter, 1u);
+        q = uni(q);
+        if (q >= p.nq) break;
+
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = lane * 4; i < p.dim; i += 256)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        if (MODE == VIS_LDS) {
+            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;
+            for (uint32_t i = lane; i < n16; i += 64) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            epoch++;
+            if (epoch == 256u) {
+                for (u64 i = (u64)lane * 16; i < p.tag_stride; i += 1024)
+                    *reinterpret_cast<uint4 *>(tags + i) = make_uint4(0, 0, 0, 0);
+                __threadfence();
+                epoch = 1;
+            }
+        }
+        // entry points (:304-316): scored, inserted, marked
+        const bool isinit = (uint32_t)lane < p.n_init;
+        const uint32_t iid = isinit ? p.init_ids[(u64)q * p.n_init + lane] : 0u;
+        if (isinit) cid[lane] = iid;
+        wave_sync();
+        score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, p.n_init, lane);
+        wave_sync();
+        if (lane == 0) pool[0] = ck[0];
+        wave_sync();
+        uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
+        merge_candidates(pool, ck, p.n_init, L, psize, cur, lane);  // ck[0] again: dropped as a duplicate
+        (void)visited_filter<MODE>(isinit, iid, vis, sets_mask, p.vis_sets_log2, tags, epoch);
+        wave_sync();
+
+        while (cur < psize) {
+            const u64 e = pool[cur];
+            const uint32_t v = (uint32_t)e >> 1;
+            if (lane == 0) pool[cur] = e | 1ull;
+            wave_sync();
+            {
+                uint32_t found = psize;
+                for (uint32_t c = cur + 1; c < psize; c += 64) {
+                    const uint32_t kidx = c + (uint32_t)lane;
+                    const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                    const u64 b = __ballot(unf);
+                    if (b) {
+                        found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                        break;
+                    }
+                }
+                cur = found;
+            }
+            ++hops;
+            const u64 b0 = p.bp_off[v], b1 = p.bp_off[v + 1];
+            scanned += (uint32_t)(b1 - b0);
+            uint32_t cnt = 0;  // survivors waiting in cid[0, cnt)
+            for (u64 r = b0; r < b1; r += 64) {
+                // this lane's query node and the extent of its row
+                const bool hasq = r + (u64)lane < b1;
+                u64 s0 = 0;
+                uint32_t len = 0;
+                if (hasq) {
+                    const uint32_t qn = p.bp_nbrs[r + lane];
+                    s0 = p.bp_off[qn];
+                    len = (uint32_t)(p.bp_off[qn + 1] - s0);
+                }
+                uint32_t incl = len;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(incl, d);
+                    if (lane >= d) incl += y;
+                }
+                const uint32_t total = lane_u32(incl, 63);
+                rstart[lane] = s0;
+                rpre[lane] = incl - len;
+                scanned += total;
+                wave_sync();
+                for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+                    const uint32_t c = c0 + (uint32_t)lane;
+                    const bool has = c < total;
+                    uint32_t own = 0;  // last row whose prefix is <= c (empty rows share a prefix with their successor)
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1)
+                        if (rpre[own + step] <= c) own += step;
+                    uint32_t nb = 0;
+                    if (has) nb = p.bp_nbrs[rstart[own] + (c - rpre[own])];
+                    bool fresh = visited_filter<MODE>(has, nb, vis, sets_mask, p.vis_sets_log2, tags, epoch);
+                    // the same node twice in this chunk: the later lane is the repeat (:331-334)
+                    for (u64 it = __ballot(fresh); it;) {
+                        const int j = __ffsll((long long)it) - 1;
+                        it &= it - 1;
+                        const uint32_t idj = lane_u32(nb, j);
+                        if (lane > j && nb == idj) fresh = false;
+                    }
+                    const u64 fm = __ballot(fresh);
+                    const uint32_t m = (uint32_t)__popcll(fm);
+                    if (m == 0) continue;
+                    if (fresh) cid[cnt + lanes_below(fm)] = nb;
+                    cnt += m;
+                    cmps += m;  // :342
+                    wave_sync();
+                    if (cnt >= 64) {
+                        score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, 64, lane);
+                        wave_sync();
+                        merge_candidates(pool, ck, 64, L, psize, cur, lane);
+                        const uint32_t rest = cnt - 64;
+                        const uint32_t tmp = ((uint32_t)lane < rest) ? cid[64 + lane] : 0u;
+                        wave_sync();
+                        if ((uint32_t)lane < rest) cid[lane] = tmp;
+                        cnt = rest;
+                        wave_sync();
+                    }
+                }
+                wave_sync();  // rstart / rpre are rewritten by the next 64 query nodes
+            }
+            if (cnt) {
+                score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, cnt, lane);
+                wave_sync();
+                merge_candidates(pool, ck, cnt, L, psize, cur, lane);
+            }
+        }
+
+        for (uint32_t i = lane; i < p.k; i += 64) {
+            uint32_t id = 0xFFFFFFFFu;
+            float d = __builtin_inff();
+            if (i < psize) {
+                const u64 e = pool[i];
+                id = (uint32_t)e >> 1;
+                d = ord2f((uint32_t)(e >> 32));
+            }
+            p.out_ids[(u64)q * p.k + i] = id;
+            p.out_dists[(u64)q * p.k + i] = d;
+        }
+        if (lane == 0) {
+            if (p.out_cmps) p.out_cmps[q] = cmps;
+            if (p.out_hops) p.out_hops[q] = hops;
+            if (p.out_scanned) p.out_scanned[q] = scanned;
+            if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+        }
+        wave_sync();
+    }
+    if (MODE == VIS_EXACT && lane == 0) p.epochs[blockIdx.x] = epoch;
+}
+
 // distance-only kernel: one wave per query, m explicit ids each (parity surface for A2/A3)
 template <bool IP>
 __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams p) {
@@ -633,6 +807,13 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 
 template <int MODE, bool IP>
 const void *pick_nch(uint32_t dim, int mw) {
+    if (mw == 2) {  // bipartite two-hop walk
+        switch (dim >> 4) {
+            case 8: return (const void *)roar_bipartite_kernel<MODE, IP, 8>;
+            case 12: return (const void *)roar_bipartite_kernel<MODE, IP, 12>;
+            default: return (const void *)roar_bipartite_kernel<MODE, IP, 0>;
+        }
+    }
     switch (dim >> 4) {
         case 8:  // D = 128 (136)
             return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 8> : (const void *)roar_search_kernel<MODE, IP, 8>;
@@ -660,7 +841,7 @@ extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int 
     }
     RoarSearchParams params = *p;
     void *args[] = {&params};
-    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave ? 256 : 64), args, p->lds_bytes, (hipStream_t)stream);
+    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave == 1 ? 256 : 64), args, p->lds_bytes, (hipStream_t)stream);
 }
 
 extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
@@ -670,7 +851,7 @@ extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave ? 256 : 64, lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave == 1 ? 256 : 64, lds_bytes);
 }
 
 extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {

@@ -207,6 +207,101 @@ class IndexBipartite:
             C.c_void_p(st.cuda_stream)))
         return out
 
+    # ---- bipartite two-hop variant (index_bipartite.cpp:42-141, 235-356, 2045-2071) ---------------
+    def Load(self, filename):
+        """IndexBipartite::Load, index_bipartite.cpp:2060-2071"""
+        capi.check(self._lib.roar_load_bipartite_file(self._h, str(filename).encode()))
+
+    def Save(self, filename):
+        """IndexBipartite::Save, index_bipartite.cpp:2045-2058"""
+        capi.check(self._lib.roar_save_bipartite_file(self._h, str(filename).encode()))
+
+    def SetBipartiteGraph(self, offsets, nbrs):
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        if nbrs.size == 0:
+            nbrs = np.zeros(1, np.uint32)
+        capi.check(self._lib.roar_set_bipartite_csr(self._h, len(offsets) - 1, capi.u64p(offsets), capi.u32p(nbrs)))
+
+    def GetBipartiteGraph(self):
+        n, ne = C.c_uint64(), C.c_uint64()
+        capi.check(self._lib.roar_get_bipartite_csr(self._h, C.byref(n), C.byref(ne), None, None))
+        offsets = np.zeros(n.value + 1, np.uint64)
+        nbrs = np.zeros(max(ne.value, 1), np.uint32)
+        capi.check(self._lib.roar_get_bipartite_csr(self._h, None, None, capi.u64p(offsets), capi.u32p(nbrs)))
+        return offsets, nbrs[:ne.value]
+
+    def BuildBipartite(self, n_sq, sq_data, n_bp, bp_data, parameters):
+        """index_bipartite.cpp:42-141 -> qbaseNNbipartite :235-280; like BuildRoarGraph the training queries
+        enter only through the kNN lists (LoadLearnBaseKNN)."""
+        if bp_data is not None:
+            self.SetBaseData(np.asarray(bp_data, np.float32)[:n_bp])
+        knn = getattr(self, "_learn_base_knn", None)
+        if knn is None:
+            raise RoarError(capi.ERR_ARG, "learn base knn file error")
+        knn = np.ascontiguousarray(knn, np.uint32)
+        capi.check(self._lib.roar_build_bipartite(self._h, capi.u32p(knn), knn.shape[0], knn.shape[1],
+                                                  parameters.Get("M_pjbp", int)))
+
+    @staticmethod
+    def BipartiteEntryIds(seed, nq, n_init, n_base):
+        """The generator that stands in for std::random_device (index_bipartite.cpp:287-294)."""
+        out = np.zeros((nq, n_init), np.uint32)
+        capi.check(capi.lib().roar_bipartite_entry_ids(int(seed), int(nq), int(n_init), int(n_base), capi.u32p(out)))
+        return out
+
+    def SearchBipartiteGraphBatch(self, queries, k, L_pq, init_ids=None, n_init=10):
+        """index_bipartite.cpp:282-356 for a batch.  init_ids [nq, n_init] u32 or None (library draws them)."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        nq, qs = queries.shape
+        if init_ids is not None:
+            init_ids = np.ascontiguousarray(init_ids, np.uint32)
+            assert init_ids.shape[0] == nq
+            n_init = init_ids.shape[1]
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        cmps = np.zeros(nq, np.uint32)
+        hops = np.zeros(nq, np.uint32)
+        rc = self._lib.roar_search_bipartite_batch(self._h, capi.f32p(queries), nq, qs, int(k), int(L_pq),
+                                                   capi.u32p(init_ids) if init_ids is not None else None, int(n_init),
+                                                   capi.u32p(ids), capi.f32p(dists), capi.u32p(cmps), capi.u32p(hops))
+        if rc == capi.ERR_SHORT:
+            raise RoarError(rc, self._lib.roar_last_error().decode())
+        capi.check(rc)
+        return dict(ids=ids, dists=dists, cmps=cmps, hops=hops)
+
+    def SearchBipartiteGraph(self, query, k, qid, parameters, indices=None, res_dists=None):
+        """One query, the reference's signature; returns (cmps, hops)."""
+        r = self.SearchBipartiteGraphBatch(np.asarray(query, np.float32).reshape(1, -1), k, parameters.Get("L_pq", int))
+        if indices is not None:
+            indices[:k] = r["ids"][0]
+        if res_dists is not None:
+            res_dists[:k] = r["dists"][0]
+        return int(r["cmps"][0]), int(r["hops"][0])
+
+    def SearchBipartiteGraphBatchDevice(self, queries, k, L_pq, init_ids, out=None, stream=None):
+        """Device-resident form (torch tensors in HBM; init_ids int32 [nq, n_init])."""
+        import torch
+
+        nq = queries.shape[0]
+        dev = queries.device
+        if out is None:
+            out = dict(ids=torch.empty((nq, k), dtype=torch.int32, device=dev),
+                       dists=torch.empty((nq, k), dtype=torch.float32, device=dev),
+                       cmps=torch.empty(nq, dtype=torch.int32, device=dev),
+                       hops=torch.empty(nq, dtype=torch.int32, device=dev),
+                       scanned=torch.empty(nq, dtype=torch.int32, device=dev),
+                       short=torch.zeros(1, dtype=torch.int32, device=dev))
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        capi.check(self._lib.roar_search_bipartite_batch_device(
+            self._h, C.c_void_p(queries.data_ptr()), nq, queries.shape[1], int(k), int(L_pq),
+            C.c_void_p(init_ids.data_ptr()), init_ids.shape[1],
+            C.c_void_p(out["ids"].data_ptr()), C.c_void_p(out["dists"].data_ptr()),
+            C.c_void_p(out["cmps"].data_ptr()), C.c_void_p(out["hops"].data_ptr()),
+            C.c_void_p(out["scanned"].data_ptr()), C.c_void_p(out["short"].data_ptr()),
+            C.c_void_p(st.cuda_stream)))
+        return out
+
     def ExactKnnDevice(self, queries, k, want_dists=True, stream=None):
         """Brute-force top-k of every query among the loaded base rows (roar_exact_knn_device): the
         generator of ground-truth / learn->base kNN files.  queries: CUDA/HIP tensor [nq, stride]."""

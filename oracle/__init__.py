@@ -90,6 +90,10 @@ def lib(impl="port"):
     nm.restype = None
     nm.argtypes = [fp, C.c_uint64]
     getattr(l, pre + "max_threads").restype = C.c_int
+    bs = getattr(l, pre + "search_bipartite_batch")
+    bs.restype = C.c_int
+    bs.argtypes = [fp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, u64, u32, fp, C.c_uint64, C.c_uint64, C.c_uint32,
+                   C.c_uint32, u32, C.c_uint32, u32, fp, u32, u32, C.c_int]
     l._pre = pre
     _libs[impl] = l
     return l
@@ -246,3 +250,68 @@ def prune_bisearch(base, metric, tgt, cand, M):
     nr = l.oracle_prune_bisearch(_f32p(base), C.c_uint64(base.shape[1]), C.c_uint32(base.shape[1]), C.c_int(metric),
                                  C.c_uint32(tgt), _u32p(cand), C.c_uint32(len(cand)), C.c_uint32(M), _u32p(res))
     return res[:nr].copy()
+
+
+# ---- bipartite two-hop variant ------------------------------------------------
+def search_bipartite_batch(base, offsets, nbrs, queries, k, L, metric, init_ids, threads=1, impl="port", dim=None):
+    """SearchBipartiteGraph (src/index_bipartite.cpp:282-356) with explicit entry points [nq, n_init]."""
+    base = np.ascontiguousarray(base, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    nbrs = np.ascontiguousarray(nbrs, np.uint32)
+    init_ids = np.ascontiguousarray(init_ids, np.uint32)
+    n, stride = base.shape
+    nq, qstride = queries.shape
+    dim = int(dim if dim is not None else stride)
+    ids = np.zeros((nq, k), np.uint32)
+    dists = np.zeros((nq, k), np.float32)
+    cmps = np.zeros(nq, np.uint32)
+    hops = np.zeros(nq, np.uint32)
+    l = lib(impl)
+    rc = getattr(l, l._pre + "search_bipartite_batch")(
+        _f32p(base), n, stride, dim, int(metric), _u64p(offsets), _u32p(nbrs), _f32p(queries), qstride, nq, int(k),
+        int(L), _u32p(init_ids), init_ids.shape[1], _u32p(ids), _f32p(dists), _u32p(cmps), _u32p(hops), int(threads))
+    return dict(ids=ids, dists=dists, cmps=cmps, hops=hops, short=rc)
+
+
+def build_bipartite(learn_knn, n_base, M_pjbp):
+    """qbaseNNbipartite (src/index_bipartite.cpp:235-280) -> offsets u64[n_base + n_learn + 1], nbrs u32."""
+    learn_knn = np.ascontiguousarray(learn_knn, np.uint32)
+    nl, K = learn_knn.shape
+    offsets = np.zeros(n_base + nl + 1, np.uint64)
+    nbrs = np.zeros(nl * min(K, M_pjbp) + 1, np.uint32)
+    l = lib("port")
+    l.oracle_build_bipartite.restype = None
+    l.oracle_build_bipartite(_u32p(learn_knn), C.c_uint32(nl), C.c_uint32(K), C.c_uint32(n_base), C.c_uint32(M_pjbp),
+                             _u64p(offsets), _u32p(nbrs))
+    return offsets, nbrs[:int(offsets[-1])]
+
+
+def bipartite_save(path, offsets, nbrs):
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    nbrs = np.ascontiguousarray(nbrs, np.uint32)
+    if lib("port").oracle_bipartite_save(path.encode(), C.c_uint32(len(offsets) - 1), _u64p(offsets), _u32p(nbrs)):
+        raise RuntimeError("cannot open file")
+
+
+def bipartite_load(path):
+    l = lib("port")
+    npts, ne = C.c_uint32(), C.c_uint64()
+    rc = l.oracle_bipartite_load(path.encode(), C.byref(npts), C.byref(ne), None, None)
+    if rc:
+        raise RuntimeError("cannot open file" if rc == -1 else "graph file truncated")
+    offsets = np.zeros(npts.value + 1, np.uint64)
+    nbrs = np.zeros(max(ne.value, 1), np.uint32)
+    if l.oracle_bipartite_load(path.encode(), C.byref(npts), C.byref(ne), _u64p(offsets), _u32p(nbrs)):
+        raise RuntimeError("graph file truncated")
+    return offsets, nbrs[:ne.value]
+
+
+def rderr(gt_dists, res_dists, k, metric):
+    """ComputeRderr, tests/test_search_bipartite.cpp:38-62."""
+    gt_dists = np.ascontiguousarray(gt_dists, np.float32)
+    res_dists = np.ascontiguousarray(res_dists, np.float32)
+    l = lib("port")
+    l.oracle_rderr.restype = C.c_double
+    return float(l.oracle_rderr(_f32p(gt_dists), C.c_uint32(gt_dists.shape[1]), _f32p(res_dists),
+                                C.c_uint32(res_dists.shape[0]), C.c_uint32(k), C.c_int(metric)))

@@ -15,7 +15,8 @@
 // submodules are empty, so index_bipartite.cpp is unbuildable here without stand-ins.
 // ref_search_batch below therefore restates the SearchRoarGraph loop
 // (src/index_bipartite.cpp:2311-2420) over the real queue / visited pool / distance
-// objects, and the metric -> distance choice of Index::Index (src/index.cpp:8-25).
+// objects, and the metric -> distance choice of Index::Index (src/index.cpp:8-25);
+// ref_search_bipartite_batch does the same for SearchBipartiteGraph (:282-356).
 #include <omp.h>
 
 #include <cstdint>
@@ -133,6 +134,61 @@ int ref_search_batch(const float *base, uint64_t n, uint64_t stride, uint32_t di
         cmps_out[qi] = cmps;
         hops_out[qi] = hops;
         if (scanned_out) scanned_out[qi] = scanned;
+        if (search_queue.size() < k) {
+            short_count++;
+            continue;
+        }
+        for (uint32_t i = 0; i < k; ++i) {
+            ids[(uint64_t)qi * k + i] = search_queue[i].id;
+            dists[(uint64_t)qi * k + i] = search_queue[i].distance;
+        }
+    }
+    delete distance_;
+    return short_count;
+}
+
+// SearchBipartiteGraph loop (src/index_bipartite.cpp:282-356) restated over the reference's own queue /
+// visited list / distance objects; entry points are an argument instead of std::random_device draws.
+int ref_search_bipartite_batch(const float *base, uint64_t n_base, uint64_t stride, uint32_t dim, int metric,
+                               const uint64_t *offsets, const uint32_t *nbrs, const float *queries, uint64_t qstride,
+                               uint64_t nq, uint32_t k, uint32_t L, const uint32_t *init_ids, uint32_t n_init,
+                               uint32_t *ids, float *dists, uint32_t *cmps_out, uint32_t *hops_out, int threads) {
+    if (threads <= 0) threads = omp_get_num_procs();
+    efanna2e::Distance *distance_ = make_distance(metric);
+    VisitedListPool pool(threads, (int)n_base);
+    int short_count = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : short_count)
+    for (int64_t qi = 0; qi < (int64_t)nq; ++qi) {
+        const float *query = queries + (uint64_t)qi * qstride;
+        efanna2e::NeighborPriorityQueue search_queue(L);
+        VisitedList *vl = pool.getFreeVisitedList();
+        vl_type *visited_array = vl->mass;
+        vl_type visited_array_tag = vl->curV;
+        for (uint32_t i = 0; i < n_init; ++i) {
+            uint32_t id = init_ids[(uint64_t)qi * n_init + i];
+            float d = distance_->compare(base + (uint64_t)id * stride, query, dim);
+            search_queue.insert(efanna2e::Neighbor(id, d, false));
+            visited_array[id] = visited_array_tag;
+        }
+        uint32_t cmps = 0, hops = 0;
+        while (search_queue.has_unexpanded_node()) {
+            auto cur = search_queue.closest_unexpanded();
+            hops++;
+            for (uint64_t a = offsets[cur.id]; a < offsets[cur.id + 1]; ++a) {
+                uint32_t nbr = nbrs[a];
+                for (uint64_t b = offsets[nbr]; b < offsets[nbr + 1]; ++b) {
+                    uint32_t ns = nbrs[b];
+                    if (visited_array[ns] == visited_array_tag) continue;
+                    visited_array[ns] = visited_array_tag;
+                    float d = distance_->compare(base + (uint64_t)ns * stride, query, dim);
+                    ++cmps;
+                    search_queue.insert(efanna2e::Neighbor(ns, d, false));
+                }
+            }
+        }
+        pool.releaseVisitedList(vl);
+        cmps_out[qi] = cmps;
+        hops_out[qi] = hops;
         if (search_queue.size() < k) {
             short_count++;
             continue;

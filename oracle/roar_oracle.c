@@ -284,6 +284,162 @@ int oracle_search_batch(const float *base, uint64_t n, uint64_t stride, uint32_t
     return short_count;
 }
 
+/* ---------------------------------------------------------------- F4: bipartite two-hop variant */
+/* SearchBipartiteGraph, src/index_bipartite.cpp:282-356.  The reference draws its 10 entry points from
+ * std::random_device (:287-294); here they are an argument so that a run can be replayed on the GPU.
+ * Graph: CSR over base nodes [0, n_base) and training-query nodes [n_base, n_total). */
+static int search_bipartite_one(const float *base, uint64_t stride, uint32_t dim, int metric, const uint64_t *offsets,
+                                const uint32_t *nbrs, const uint32_t *init_ids, uint32_t n_init, const float *query,
+                                uint32_t k, uint32_t L, oracle_visited *vl, oracle_pq *q, uint32_t *ids, float *dists,
+                                uint32_t *cmps_out, uint32_t *hops_out) {
+    q->size = 0; q->cur = 0; q->capacity = L;
+    visited_reset(vl);
+    uint16_t tag = vl->curV;
+    uint16_t *mass = vl->mass;
+    for (uint32_t i = 0; i < n_init; ++i) { /* :304-316: scored, inserted, marked */
+        uint32_t id = init_ids[i];
+        oracle_pq_insert(q, id, oracle_dist(metric, base + (uint64_t)id * stride, query, dim));
+        mass[id] = tag;
+    }
+    uint32_t cmps = 0, hops = 0;
+    while (q->cur < q->size) { /* :320 */
+        oracle_nbr cur = oracle_pq_closest_unexpanded(q);
+        hops++; /* :323, before the empty-row test :324-326 */
+        for (uint64_t a = offsets[cur.id]; a < offsets[cur.id + 1]; ++a) {     /* :327 */
+            uint32_t nbr = nbrs[a];
+            for (uint64_t b = offsets[nbr]; b < offsets[nbr + 1]; ++b) {       /* :329 */
+                uint32_t ns = nbrs[b];
+                if (mass[ns] == tag) continue;                                 /* :330-332 */
+                mass[ns] = tag;                                                /* :334 */
+                float d = oracle_dist(metric, base + (uint64_t)ns * stride, query, dim);
+                ++cmps;                                                        /* :340 */
+                oracle_pq_insert(q, ns, d);
+            }
+        }
+    }
+    *cmps_out = cmps; *hops_out = hops;
+    if (q->size < k) return -1; /* :347-351 */
+    for (uint32_t i = 0; i < k; ++i) {
+        ids[i] = q->data[i].id;
+        dists[i] = q->data[i].distance;
+    }
+    return 0;
+}
+
+/* loop shape of tests/test_search_bipartite.cpp:194-201 */
+int oracle_search_bipartite_batch(const float *base, uint64_t n_base, uint64_t stride, uint32_t dim, int metric,
+                                  const uint64_t *offsets, const uint32_t *nbrs, const float *queries, uint64_t qstride,
+                                  uint64_t nq, uint32_t k, uint32_t L, const uint32_t *init_ids, uint32_t n_init,
+                                  uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops, int threads) {
+    int short_count = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_num_procs();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel num_threads(threads) reduction(+ : short_count)
+    {
+        oracle_visited vl;
+        visited_init(&vl, n_base); /* only base ids are ever marked (:315, :334) */
+        memset(vl.mass, 0, sizeof(uint16_t) * (n_base ? n_base : 1));
+        oracle_pq q;
+        oracle_pq_init(&q, L);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t i = 0; i < (int64_t)nq; ++i) {
+            int rc = search_bipartite_one(base, stride, dim, metric, offsets, nbrs, init_ids + (uint64_t)i * n_init,
+                                          n_init, queries + (uint64_t)i * qstride, k, L, &vl, &q,
+                                          ids + (uint64_t)i * k, dists + (uint64_t)i * k, &cmps[i], &hops[i]);
+            if (rc) short_count++;
+        }
+        oracle_pq_free(&q);
+        free(vl.mass);
+    }
+    return short_count;
+}
+
+/* qbaseNNbipartite, src/index_bipartite.cpp:235-280, sequential (sq ascending; the reference's OpenMP
+ * loop appends to the target rows in lock order).  offsets has n_base + n_learn + 1 entries, nbrs room
+ * for n_learn * min(K, M_pjbp) ids. */
+void oracle_build_bipartite(const uint32_t *learn_knn, uint32_t n_learn, uint32_t K, uint32_t n_base, uint32_t M_pjbp,
+                            uint64_t *offsets, uint32_t *nbrs) {
+    uint32_t keep = K < M_pjbp ? K : M_pjbp; /* :256-259 */
+    uint64_t nt = (uint64_t)n_base + n_learn;
+    uint32_t *deg = (uint32_t *)calloc(nt, sizeof(uint32_t));
+    for (uint32_t sq = 0; sq < n_learn; ++sq) {
+        const uint32_t *nn = learn_knn + (uint64_t)sq * K;
+        uint32_t tgt = nn[0]; /* choose_tgt = 0, :260-262 */
+        for (uint32_t i = 0; i < keep; ++i)
+            if (nn[i] != tgt) deg[n_base + sq]++; /* :263-268 */
+        deg[tgt]++;                               /* :269-272 */
+    }
+    offsets[0] = 0;
+    for (uint64_t v = 0; v < nt; ++v) offsets[v + 1] = offsets[v] + deg[v];
+    memset(deg, 0, nt * sizeof(uint32_t));
+    for (uint32_t sq = 0; sq < n_learn; ++sq) {
+        const uint32_t *nn = learn_knn + (uint64_t)sq * K;
+        uint32_t tgt = nn[0];
+        for (uint32_t i = 0; i < keep; ++i)
+            if (nn[i] != tgt) nbrs[offsets[n_base + sq] + deg[n_base + sq]++] = nn[i];
+        nbrs[offsets[tgt] + deg[tgt]++] = n_base + sq;
+    }
+    free(deg);
+}
+
+/* IndexBipartite::Save / Load, src/index_bipartite.cpp:2045-2071: u32 npts; npts x {u32 deg; u32 nbr[deg]} */
+int oracle_bipartite_save(const char *path, uint32_t npts, const uint64_t *offsets, const uint32_t *nbrs) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    fwrite(&npts, 4, 1, f);
+    for (uint32_t i = 0; i < npts; ++i) {
+        uint32_t deg = (uint32_t)(offsets[i + 1] - offsets[i]);
+        fwrite(&deg, 4, 1, f);
+        fwrite(nbrs + offsets[i], 4, deg, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int oracle_bipartite_load(const char *path, uint32_t *npts, uint64_t *nedges, uint64_t *offsets, uint32_t *nbrs) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    if (fread(npts, 4, 1, f) != 1) { fclose(f); return -2; }
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < *npts; ++i) {
+        uint32_t deg;
+        if (fread(&deg, 4, 1, f) != 1) { fclose(f); return -2; }
+        if (offsets) offsets[i] = tot;
+        if (nbrs) {
+            if (fread(nbrs + tot, 4, deg, f) != deg) { fclose(f); return -2; }
+        } else {
+            fseek(f, (long)deg * 4, SEEK_CUR);
+        }
+        tot += deg;
+    }
+    if (offsets) offsets[*npts] = tot;
+    *nedges = tot;
+    fclose(f);
+    return 0;
+}
+
+/* ComputeRderr, tests/test_search_bipartite.cpp:38-62: mean over queries of the mean over the k ranks of
+ * |r - g| / g with r the returned distance turned back into the ground truth's convention
+ * (INNER_PRODUCT: -d; COSINE: 2 (1 + d)), float temporaries as there. */
+double oracle_rderr(const float *gt_dist, uint32_t gt_dim, const float *res_dists, uint32_t nq, uint32_t k, int metric) {
+    double total_err = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        double err = 0.0;
+        for (uint32_t j = 0; j < k; ++j) {
+            float r = res_dists[(uint64_t)i * k + j];
+            if (metric == 1) r = (float)(-1.0 * r);                       /* :46-49 */
+            else if (metric == 4) r = (float)(2.0 * (1.0 - (-1.0 * r)));  /* :50-53 */
+            float g = gt_dist[(uint64_t)i * gt_dim + j];
+            err += fabsf(r - g) / (double)g;                              /* :57 */
+        }
+        total_err += err / (double)k;
+    }
+    return total_err / (double)nq;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_num_procs();

@@ -12,6 +12,10 @@ text is stored.
 Files per search case <name> in {l2_128, ip_200, cos_512}:
   <name>.base.fbin  <name>.query.fbin  <name>.roar.index  <name>.gt.ibin
   <name>.expected.npz : for L in LS: ids_L, dists_L, cmps_L, hops_L, scanned_L  (k = 10)
+  bipartite two-hop variant, cases in BIPARTITE: <name>.bipartite.index (IndexBipartite::Save format, built by
+  the restated qbaseNNbipartite from exact learn->base lists, M_pjbp = 35) and <name>.bipartite.expected.npz:
+  init_ids [nq, 10] (seeded stand-in for the reference's std::random_device draws) and ids_L, dists_L, cmps_L,
+  hops_L from oracle/_ref's SearchBipartiteGraph loop
 distance_kat.npz : a_D, b_D, l2_D, ip_D for D in KAT_DIMS (128 pairs each)
 pq_trace.npz     : capacity, ops, ids, dists, snap (state after every op)
 """
@@ -70,6 +74,33 @@ def make_case(name):
     np.savez_compressed(pre + ".expected.npz", **out)
 
 
+BIPARTITE = ["ip_200", "l2_128"]
+
+
+def make_bipartite_case(name):
+    gen, metric, n, nq, d = CASES[name]
+    base, q, learn = gen(n, nq, d, seed=1234, n_learn=n)
+    pre = os.path.join(HERE, name)
+    assert np.array_equal(fileio.read_fbin(pre + ".base.fbin"), base)  # same inputs as the search case
+    knn, _ = sb.exact_knn(learn, base, 100, metric)
+    off, nbrs = oracle.build_bipartite(knn, n, 35)
+    oracle.bipartite_save(pre + ".bipartite.index", off, nbrs)
+    base_l, _ = oracle.fbin_load_padded(pre + ".base.fbin", impl="ref")
+    q_l, _ = oracle.fbin_load_padded(pre + ".query.fbin", impl="ref")
+    gt_ids, _ = fileio.read_gt(pre + ".gt.ibin")
+    init = np.random.default_rng(77).integers(0, n, (nq, 10)).astype(np.uint32)
+    init[0, 1] = init[0, 0]  # a repeated entry point (the second insert is rejected as a duplicate)
+    out = {"init_ids": init}
+    for L in LS:
+        r = oracle.search_bipartite_batch(base_l, off, nbrs, q_l, K, L, metric, init, threads=4, impl="ref")
+        assert r["short"] == 0
+        for key in ("ids", "dists", "cmps", "hops"):
+            out[f"{key}_{L}"] = r[key]
+        print(name, "bipartite L", L, "recall@10", round(oracle.recall(r["ids"], gt_ids, K), 4), "cmps",
+              r["cmps"].mean(), "hops", r["hops"].mean())
+    np.savez_compressed(pre + ".bipartite.expected.npz", **out)
+
+
 def make_distance_kat():
     rng = np.random.default_rng(99)
     out = {}
@@ -120,8 +151,14 @@ def make_pq_trace():
 if __name__ == "__main__":
     oracle.build()
     assert oracle.have_ref(), "oracle/_ref not built"
+    only_bipartite = "--bipartite-only" in sys.argv
     for name in CASES:
-        make_case(name)
+        if not only_bipartite:
+            make_case(name)
+    for name in BIPARTITE:
+        make_bipartite_case(name)
+    if only_bipartite:
+        sys.exit(0)
     make_distance_kat()
     make_pq_trace()
     print("golden fixtures written to", HERE)

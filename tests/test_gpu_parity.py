@@ -669,3 +669,151 @@ def test_cli_pipeline_from_fbin_files_only(tmp_path, built_lib):
     rows = [r.split(",") for r in open(P["eval.csv"]).read().strip().splitlines()]
     assert [int(r[0]) for r in rows] == [10, 50]
     assert float(rows[1][4]) > 0.97 and float(rows[1][4]) >= float(rows[0][4])
+
+
+# ---- bipartite two-hop variant: SearchBipartiteGraph (index_bipartite.cpp:282-356), SURVEY 8(f) row 4 ----
+@pytest.mark.parametrize("case,metric", [("ip_200", 1), ("l2_128", 0)])
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+def test_bipartite_search_matches_reference_golden(case, metric, mode, golden_dir, tmp_path, built_lib):
+    from mysteryann_amd import fileio
+    from mysteryann_amd import index as mi
+
+    exp = np.load(os.path.join(golden_dir, case + ".bipartite.expected.npz"))
+    q = fileio.read_fbin(os.path.join(golden_dir, case + ".query.fbin"))
+    idx = mi.IndexBipartite(q.shape[1], 0, metric, None)
+    idx.LoadSearchNeededData(os.path.join(golden_dir, case + ".base.fbin"))
+    src = os.path.join(golden_dir, case + ".bipartite.index")
+    idx.Load(src)  # tests/test_search_bipartite.cpp:160
+    idx.set_option("visited_mode", mode)
+    for L in LS:
+        r = idx.SearchBipartiteGraphBatch(q, K, L, exp["init_ids"])
+        for key in ("ids", "dists", "hops", "cmps"):  # 2000 base points: the LDS table cannot overflow
+            assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, L, key)
+    out = str(tmp_path / "b.index")
+    idx.Save(out)
+    assert open(src, "rb").read() == open(out, "rb").read()
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_bipartite_random_graphs_against_oracle(metric, built_lib):
+    """Hub rows (> 64 query nodes in one hop), empty rows, ids repeated inside a hop, 1 / 10 / 64 entry
+    points with repeats, pools shorter and longer than what is reachable."""
+    import oracle
+    from mysteryann_amd import index as mi
+    from tests.test_oracle_pinning import _random_bipartite
+
+    rng = np.random.default_rng(100 + metric)
+    nb, nl, d = 3000, 2000, 72
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    q = rng.standard_normal((96, d)).astype(np.float32)
+    off, nbrs = _random_bipartite(rng, nb, nl, max_q=8, max_b=40, hub=11)
+    for mode in (0, 1):
+        idx = mi.IndexBipartite(d, nb, metric, None)
+        idx.SetBaseData(base)
+        idx.SetBipartiteGraph(off, nbrs)
+        idx.set_option("visited_mode", mode)
+        assert idx.info("bipartite_nodes") == nb + nl and idx.info("bipartite_edges") == len(nbrs)
+        o2, n2 = idx.GetBipartiteGraph()
+        assert np.array_equal(o2, off) and np.array_equal(n2, nbrs)
+        for n_init in (1, 10, 64):
+            init = rng.integers(0, nb, (96, n_init)).astype(np.uint32)
+            init[::2, 0] = 11  # half of the queries start on the hub
+            if n_init > 1:
+                init[:, 1] = init[:, 0]
+            else:
+                init[:, 0] = 11  # a single entry point on an empty row would end the search short of k
+            for L in (5, 33, 200, 700):
+                o = oracle.search_bipartite_batch(base, off, nbrs, q, 5, L, metric, init, threads=4)
+                assert o["short"] == 0
+                r = idx.SearchBipartiteGraphBatch(q, 5, L, init)
+                for key in ("ids", "dists", "hops"):
+                    assert np.array_equal(r[key], o[key]), (mode, n_init, L, key)
+                if mode == 0:
+                    assert np.array_equal(r["cmps"], o["cmps"]), (n_init, L)
+                else:
+                    assert (r["cmps"] >= o["cmps"]).all()
+        idx.close()
+
+
+def test_bipartite_build_and_generated_entry_points(tmp_path, built_lib):
+    """BuildBipartite (qbaseNNbipartite) from kNN lists == the restated builder; entry points drawn by the
+    library (init_ids = NULL) are reproducible from the seed; error behaviour of the reference."""
+    import oracle
+    from mysteryann_amd import fileio, synth
+    from mysteryann_amd import index as mi
+    from mysteryann_amd.capi import ERR_ARG, ERR_FORMAT, ERR_SHORT, RoarError
+    from tests.golden.small_builder import exact_knn
+
+    n, nl = 4000, 3000
+    base, q, learn = synth.t2i_numpy(n, 80, 200, seed=5, n_learn=nl)
+    knn, _ = exact_knn(learn, base, 50, 1)
+    p = str(tmp_path / "learn.nn.ibin")
+    fileio.write_knn(p, knn)
+    idx = mi.IndexBipartite(200, n + nl, mi.INNER_PRODUCT, None)
+    idx.LoadLearnBaseKNN(p)
+    par = mi.Parameters()
+    par.Set("M_pjbp", 35)
+    idx.BuildBipartite(nl, None, n, base, par)  # tests/test_only_build_bipartite.cpp:129
+    off, nbrs = idx.GetBipartiteGraph()
+    woff, wnbrs = oracle.build_bipartite(knn, n, 35)
+    assert np.array_equal(off, woff) and np.array_equal(nbrs, wnbrs)
+    sp = str(tmp_path / "bp.index")
+    idx.Save(sp)
+    wp = str(tmp_path / "bp_want.index")
+    oracle.bipartite_save(wp, woff, wnbrs)
+    assert open(sp, "rb").read() == open(wp, "rb").read()
+    # library-drawn entry points: the stand-in for std::random_device is reproducible from the seed
+    idx.set_option("visited_mode", 0)
+    idx.set_option("bipartite_seed", 42)
+    r = idx.SearchBipartiteGraphBatch(q, K, 100)
+    init = mi.IndexBipartite.BipartiteEntryIds(42, len(q), 10, n)
+    assert init.max() < n and len(np.unique(init)) > 5 * len(q)
+    bp = fileio.pad_rows(base)
+    o = oracle.search_bipartite_batch(bp, woff, wnbrs, fileio.pad_rows(q), K, 100, 1, init, threads=4)
+    for key in ("ids", "dists", "cmps", "hops"):
+        assert np.array_equal(r[key], o[key]), key
+    r2 = idx.SearchBipartiteGraphBatch(q, K, 100)  # the seed advances: a fresh draw, as in the reference
+    assert not np.array_equal(r2["cmps"], r["cmps"])
+    # one query through the reference's signature
+    par.Set("L_pq", 100)
+    idx.set_option("bipartite_seed", 42)
+    ind, dd = np.zeros(K, np.uint32), np.zeros(K, np.float32)
+    cmps, hops = idx.SearchBipartiteGraph(q[0], K, 0, par, ind, dd)
+    assert (cmps, hops) == (int(o["cmps"][0]), int(o["hops"][0])) and np.array_equal(ind, o["ids"][0])
+    # errors
+    with pytest.raises(RoarError) as e:
+        idx.SearchBipartiteGraphBatch(q, 20, 10, init)
+    assert e.value.code == ERR_ARG and "L_pq must greater or equal than k" in str(e.value)
+    lonely = np.full((len(q), 1), int(np.setdiff1d(np.arange(n), knn[:, 0])[0]), np.uint32)  # a base node no query targets
+    with pytest.raises(RoarError) as e:
+        idx.SearchBipartiteGraphBatch(q, 2, 10, lonely)
+    assert e.value.code == ERR_SHORT and str(e.value) == "not enough results: 1, expected: 2"
+    bad_off = np.array([0, 1, 1], np.uint64)
+    with pytest.raises(RoarError) as e:  # a base node linked to a base node
+        i2 = mi.IndexBipartite(200, 2, 1, None)
+        i2.SetBaseData(base[:1])
+        i2.SetBipartiteGraph(bad_off, np.array([0], np.uint32))
+    assert e.value.code == ERR_FORMAT
+    idx.close()
+
+
+def test_bipartite_device_resident_batch(golden_dir, built_lib):
+    import torch
+    from mysteryann_amd import fileio
+    from mysteryann_amd import index as mi
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.bipartite.expected.npz"))
+    q = fileio.read_fbin(os.path.join(golden_dir, "ip_200.query.fbin"))
+    idx = mi.IndexBipartite(200, 0, 1, None)
+    idx.LoadSearchNeededData(os.path.join(golden_dir, "ip_200.base.fbin"))
+    idx.Load(os.path.join(golden_dir, "ip_200.bipartite.index"))
+    qd = torch.from_numpy(fileio.pad_rows(q)).cuda()
+    init = torch.from_numpy(exp["init_ids"].astype(np.int32)).cuda()
+    out = idx.SearchBipartiteGraphBatchDevice(qd, K, 50, init)
+    torch.cuda.synchronize()
+    assert int(out["short"].item()) == 0
+    assert np.array_equal(out["ids"].cpu().numpy().astype(np.uint32), exp["ids_50"])
+    assert np.array_equal(out["dists"].cpu().numpy(), exp["dists_50"])
+    assert np.array_equal(out["hops"].cpu().numpy().astype(np.uint32), exp["hops_50"])
+    idx.close()

@@ -146,3 +146,76 @@ def test_builder_restatement_produces_a_navigable_graph():
     tgt = int(knn[0, 0])
     kept = oracle.prune_bisearch(base, 1, tgt, knn[0, 1:], 35)
     assert len(kept) <= 35 and tgt not in kept and len(set(kept.tolist())) == len(kept)
+
+
+# ---- bipartite two-hop variant ------------------------------------------------
+def _random_bipartite(rng, nb, nl, max_q=6, max_b=12, hub=None):
+    """Rows of base nodes hold training-query nodes (>= nb), rows of training-query nodes base nodes;
+    some rows empty, repeated ids allowed; `hub` = a base node linked to more than 64 query nodes."""
+    rows = []
+    for v in range(nb):
+        deg = int(rng.integers(0, max_q)) if rng.random() < 0.7 else 0
+        rows.append(rng.integers(nb, nb + nl, deg))
+    if hub is not None:
+        rows[hub] = rng.integers(nb, nb + nl, 150)
+    for _ in range(nl):
+        rows.append(rng.integers(0, nb, int(rng.integers(0, max_b))))
+    off = np.zeros(nb + nl + 1, np.uint64)
+    off[1:] = np.cumsum([len(r) for r in rows])
+    return off, np.concatenate(rows).astype(np.uint32)
+
+
+@pytest.mark.parametrize("case,metric", [("ip_200", 1), ("l2_128", 0)])
+def test_bipartite_restatement_matches_reference_golden(case, metric, golden_dir, tmp_path):
+    base, _ = oracle.fbin_load_padded(os.path.join(golden_dir, case + ".base.fbin"))
+    q, _ = oracle.fbin_load_padded(os.path.join(golden_dir, case + ".query.fbin"))
+    src = os.path.join(golden_dir, case + ".bipartite.index")
+    off, nbrs = oracle.bipartite_load(src)
+    assert len(off) - 1 == 2 * base.shape[0]  # base + as many training queries
+    exp = np.load(os.path.join(golden_dir, case + ".bipartite.expected.npz"))
+    for L in LS:
+        r = oracle.search_bipartite_batch(base, off, nbrs, q, 10, L, metric, exp["init_ids"], threads=2)
+        assert r["short"] == 0
+        for key in ("ids", "dists", "cmps", "hops"):
+            assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, L, key)
+    out = str(tmp_path / "b.index")  # IndexBipartite::Save format round trip
+    oracle.bipartite_save(out, off, nbrs)
+    assert open(src, "rb").read() == open(out, "rb").read()
+
+
+def test_bipartite_builder_restatement():
+    """qbaseNNbipartite (index_bipartite.cpp:235-280) on hand-made lists: the first id is the target and is
+    dropped from the query's row wherever it repeats; lists longer than M_pjbp are cut first."""
+    knn = np.array([[3, 1, 2, 0], [3, 3, 0, 1], [0, 2, 1, 3]], np.uint32)
+    off, nbrs = oracle.build_bipartite(knn, 4, 3)
+    rows = [nbrs[int(off[v]):int(off[v + 1])].tolist() for v in range(7)]
+    assert rows == [[6], [], [], [4, 5], [1, 2], [0], [2, 1]]
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built or host lacks AVX-512")
+def test_bipartite_port_equals_reference_components_live():
+    rng = np.random.default_rng(21)
+    nb, nl = 1500, 900
+    base = rng.standard_normal((nb, 72)).astype(np.float32)
+    q = rng.standard_normal((25, 72)).astype(np.float32)
+    off, nbrs = _random_bipartite(rng, nb, nl, hub=7)
+    for n_init in (1, 10, 40):
+        init = rng.integers(0, nb, (25, n_init)).astype(np.uint32)
+        init[:, 0] = 7
+        for m in (0, 1):
+            for L in (10, 60, 300):
+                a = oracle.search_bipartite_batch(base, off, nbrs, q, 5, L, m, init, threads=1, impl="port")
+                b = oracle.search_bipartite_batch(base, off, nbrs, q, 5, L, m, init, threads=3, impl="ref")
+                assert a["short"] == b["short"]
+                for key in ("ids", "dists", "cmps", "hops"):
+                    assert np.array_equal(a[key], b[key]), (n_init, m, L, key)
+
+
+def test_rderr_restatement():
+    """ComputeRderr (tests/test_search_bipartite.cpp:38-62) against a direct numpy reading."""
+    rng = np.random.default_rng(3)
+    gt = rng.uniform(0.5, 2.0, (7, 20)).astype(np.float32)
+    res = (gt[:, :10] * rng.uniform(0.9, 1.1, (7, 10))).astype(np.float32)
+    want = float(np.mean(np.mean(np.abs(res - gt[:, :10]).astype(np.float32) / gt[:, :10].astype(np.float64), axis=1)))
+    assert abs(oracle.rderr(gt, res, 10, 0) - want) < 1e-12
+    assert abs(oracle.rderr(gt, -res, 10, 1) - want) < 1e-12

@@ -256,6 +256,42 @@ class IndexBipartite {
                                 nullptr));
     }
 
+    // ---- bipartite two-hop variant (the ablation baseline) ---------------------------------------
+    // index_bipartite.h:35-36, src/index_bipartite.cpp:42-141 -> qbaseNNbipartite :235-280
+    void BuildBipartite(size_t n_sq, const float *sq_data, size_t n_bp, const float *bp_data, const Parameters &parameters) {
+        (void)n_sq;
+        (void)sq_data;
+        ensure((unsigned)dimension_);
+        check(roar_set_base(h_, bp_data, n_bp, (uint32_t)((dimension_ + 7) / 8 * 8)));
+        nd_ = n_bp;
+        check(roar_build_bipartite(h_, learn_base_knn_.data(), knn_n_, knn_k_, parameters.Get<uint32_t>("M_pjbp")));
+    }
+    // index_bipartite.h:53-54, src/index_bipartite.cpp:2045-2071
+    void Save(const char *filename) { check(roar_save_bipartite_file(handle(), filename)); }
+    void Load(const char *filename) {
+        ensure((unsigned)dimension_);
+        check(roar_load_bipartite_file(h_, filename));
+    }
+    // index_bipartite.h:137-138, src/index_bipartite.cpp:282-356.  The 10 entry points are drawn by the
+    // library (the reference draws them from std::random_device, :287-294).
+    std::pair<uint32_t, uint32_t> SearchBipartiteGraph(const float *query, size_t k, size_t &qid, const Parameters &parameters,
+                                                       unsigned *indices, std::vector<float> &dists) {
+        (void)qid;
+        uint32_t L_pq = parameters.Get<uint32_t>("L_pq");
+        uint32_t cmps = 0, hops = 0;
+        if (dists.size() < k) dists.resize(k);
+        check(roar_search_bipartite_batch(handle(), query, 1, (uint32_t)dimension_, (uint32_t)k, L_pq, nullptr, 10, indices,
+                                          dists.data(), &cmps, &hops));
+        return std::make_pair(cmps, hops);
+    }
+    // New: the whole query block in one launch (tests/test_search_bipartite.cpp:194-201).  init_ids: nq x n_init
+    // base ids, or nullptr for library-drawn ones.
+    void SearchBipartiteGraphBatch(const float *queries, size_t nq, size_t k, uint32_t L_pq, const uint32_t *init_ids,
+                                   uint32_t n_init, unsigned *ids, float *dists, uint32_t *cmps, uint32_t *hops) {
+        check(roar_search_bipartite_batch(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, L_pq, init_ids, n_init,
+                                          ids, dists, cmps, hops));
+    }
+
     // exact kNN of `queries` among the loaded base rows (the producer of ground-truth / learn-base kNN files)
     void ExactKnn(const float *queries, size_t nq, size_t k, unsigned *ids, float *dists) {
         check(roar_exact_knn(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, ids, dists));

@@ -2,6 +2,8 @@
 // tests/test_build_roargraph.cpp (own code; same flags :33-58, same sequence :83-137: load base +
 // training queries, LoadLearnBaseKNN, BuildRoarGraph, SaveProjectionGraph), written against
 // include/roargraph_amd/efanna2e.h.  boost::program_options is not in this image: flags are parsed by hand.
+// With --bipartite_index_save_path it is the counterpart of tests/test_only_build_bipartite.cpp (:100-135):
+// LoadLearnBaseKNN, BuildBipartite, Save.
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -11,7 +13,7 @@
 
 int main(int argc, char **argv) {
     std::string base_data_file, sampled_query_data_file, projection_index_save_file, learn_base_nn_file, dist,
-        data_type = "float";
+        data_type = "float", bipartite_index_save_file;
     uint32_t M_sq = 32, M_pjbp = 32, L_pjpq = 32, num_threads = 1;  // defaults of :45-50
     int device = 0;
     for (int i = 1; i < argc; ++i) {
@@ -26,13 +28,15 @@ int main(int argc, char **argv) {
         if (a == "--help" || a == "-h") {
             std::cout << "--data_type float --dist <l2/ip/cosine> --base_data_path <fbin> --sampled_query_data_path <fbin>\n"
                          "--projection_index_save_path <index> --learn_base_nn_path <ibin> [--M_sq 32] [--M_pjbp 32]\n"
-                         "[--L_pjpq 32] [-T n] [--device 0]\n";
+                         "[--L_pjpq 32] [-T n] [--device 0]\n"
+                         "[--bipartite_index_save_path <index>]  build and save the bipartite graph instead\n";
             return 0;
         } else if (a == "--data_type") data_type = next();
         else if (a == "--dist") dist = next();
         else if (a == "--base_data_path") base_data_file = next();
         else if (a == "--sampled_query_data_path") sampled_query_data_file = next();
         else if (a == "--projection_index_save_path") projection_index_save_file = next();
+        else if (a == "--bipartite_index_save_path") bipartite_index_save_file = next();
         else if (a == "--learn_base_nn_path") learn_base_nn_file = next();
         else if (a == "--M_sq") M_sq = (uint32_t)std::stoul(next());
         else if (a == "--M_pjbp") M_pjbp = (uint32_t)std::stoul(next());
@@ -44,8 +48,9 @@ int main(int argc, char **argv) {
             return -1;
         }
     }
-    if (dist.empty() || base_data_file.empty() || sampled_query_data_file.empty() || projection_index_save_file.empty() ||
-        learn_base_nn_file.empty()) {
+    const bool bipartite = !bipartite_index_save_file.empty();
+    if (dist.empty() || base_data_file.empty() || sampled_query_data_file.empty() ||
+        (projection_index_save_file.empty() && !bipartite) || learn_base_nn_file.empty()) {
         std::cerr << "missing required option\n";
         return -1;
     }
@@ -73,6 +78,18 @@ int main(int argc, char **argv) {
         parameters.Set<uint32_t>("num_threads", num_threads);
         index_bipartite.LoadLearnBaseKNN(learn_base_nn_file.c_str());
         auto s = std::chrono::high_resolution_clock::now();
+        if (bipartite) {
+            index_bipartite.BuildBipartite(sq_num, data_sq, base_num, data_bp, parameters);
+            std::chrono::duration<double> diff = std::chrono::high_resolution_clock::now() - s;
+            std::cout << "indexing time: " << diff.count() << "\n";
+            index_bipartite.Save(bipartite_index_save_file.c_str());
+            std::cout << "Save index to " << bipartite_index_save_file << std::endl;
+            std::cout << "Bipartite nodes: " << index_bipartite.Info("bipartite_nodes")
+                      << " edges: " << index_bipartite.Info("bipartite_edges") << std::endl;
+            free(data_bp);
+            free(data_sq);
+            return 0;
+        }
         index_bipartite.BuildRoarGraph(sq_num, data_sq, base_num, data_bp, parameters);
         std::chrono::duration<double> diff = std::chrono::high_resolution_clock::now() - s;
         std::cout << "indexing time: " << diff.count() << "\n";

@@ -68,12 +68,15 @@ static void usage() {
                  "  --per_query                  reference loop shape: one SearchRoarGraph call per query\n"
                  "  --visited <auto|exact|lds>   visited-set policy (default auto)\n"
                  "  --rderr                      also print / save the relative distance error (7th CSV column)\n"
+                 "  --bipartite_index_save_path <index>  search the bipartite graph instead (SearchBipartiteGraph)\n"
+                 "  --entry_seed <n>             seed of the bipartite entry-point draws\n"
                  "  --device <ordinal>\n";
 }
 
 int main(int argc, char **argv) {
     std::string base_data_file, query_file, gt_file, projection_index_save_file, data_type = "float", dist;
-    std::string evaluation_save_path, visited = "auto";
+    std::string evaluation_save_path, visited = "auto", bipartite_index_save_file;
+    long long entry_seed = -1;
     bool want_rderr = false;
     std::vector<uint32_t> L_vec;
     uint32_t num_threads = omp_get_num_procs(), k = 1;
@@ -97,6 +100,8 @@ int main(int argc, char **argv) {
         else if (a == "--query_path") query_file = next();
         else if (a == "--gt_path") gt_file = next();
         else if (a == "--projection_index_save_path") projection_index_save_file = next();
+        else if (a == "--bipartite_index_save_path") bipartite_index_save_file = next();
+        else if (a == "--entry_seed") entry_seed = std::stoll(next());
         else if (a == "--evaluation_save_path") evaluation_save_path = next();
         else if (a == "--k") k = (uint32_t)std::stoul(next());
         else if (a == "-T" || a == "--num_threads") num_threads = (uint32_t)std::stoul(next());
@@ -110,6 +115,13 @@ int main(int argc, char **argv) {
             std::cerr << "unrecognised option '" << a << "'\n";
             return -1;
         }
+    }
+    // --bipartite_index_save_path: the run of tests/test_search_bipartite.cpp (Load + SearchBipartiteGraph,
+    // CSV row L_pq,qps,avg_cmps,latency,recall,rderr,avg_hops :226-231) instead of the projection-graph search
+    const bool bipartite = !bipartite_index_save_file.empty();
+    if (bipartite) {
+        projection_index_save_file = bipartite_index_save_file;
+        want_rderr = true;
     }
     if (dist.empty() || base_data_file.empty() || query_file.empty() || gt_file.empty() ||
         projection_index_save_file.empty() || L_vec.empty()) {
@@ -153,14 +165,21 @@ int main(int argc, char **argv) {
         {
             std::ifstream probe(projection_index_save_file, std::ios::binary);
             if (!probe.is_open()) {
-                std::cout << "projection index file does not exist." << std::endl;
+                std::cout << (bipartite ? "bipartite_index_save_file index file does not exist."
+                                        : "projection index file does not exist.")
+                          << std::endl;
                 return -1;
             }
         }
         efanna2e::IndexBipartite index(q_dim, base_num, dist_metric, nullptr, device);
         index.LoadSearchNeededData(base_data_file.c_str(), "");
         std::cout << "Load graph index: " << projection_index_save_file << std::endl;
-        index.LoadProjectionGraph(projection_index_save_file.c_str());
+        if (bipartite) {
+            index.Load(projection_index_save_file.c_str());
+            if (entry_seed >= 0) index.SetOption("bipartite_seed", entry_seed);
+        } else {
+            index.LoadProjectionGraph(projection_index_save_file.c_str());
+        }
         if (index.need_normalize) {
             std::cout << "Normalizing query data" << std::endl;
             for (uint32_t i = 0; i < q_pts; i++) efanna2e::normalize<float>(aligned_query_data + (size_t)i * q_dim, q_dim);
@@ -186,17 +205,26 @@ int main(int argc, char **argv) {
             parameters.Set<uint32_t>("L_pq", L_pq);
             // warm-up, :198-200 (100 queries)
             uint32_t warm = std::min<uint32_t>(100, q_pts);
-            index.SearchRoarGraphBatch(aligned_query_data, warm, k, L_pq, res.data(), res_d.data(), cmps_vec.data(),
-                                       hops_vec.data());
+            if (bipartite)
+                index.SearchBipartiteGraphBatch(aligned_query_data, warm, k, L_pq, nullptr, 10, res.data(), res_d.data(),
+                                                cmps_vec.data(), hops_vec.data());
+            else
+                index.SearchRoarGraphBatch(aligned_query_data, warm, k, L_pq, res.data(), res_d.data(), cmps_vec.data(),
+                                           hops_vec.data());
             auto start = std::chrono::high_resolution_clock::now();
             if (per_query) {
 #pragma omp parallel for schedule(dynamic, 1)
                 for (size_t i = 0; i < q_pts; ++i) {
-                    auto ret = index.SearchRoarGraph(aligned_query_data + i * q_dim, k, i, parameters, res.data() + i * k,
-                                                     res_dists[i]);
+                    auto ret = bipartite ? index.SearchBipartiteGraph(aligned_query_data + i * q_dim, k, i, parameters,
+                                                                      res.data() + i * k, res_dists[i])
+                                         : index.SearchRoarGraph(aligned_query_data + i * q_dim, k, i, parameters,
+                                                                 res.data() + i * k, res_dists[i]);
                     cmps_vec[i] = ret.first;
                     hops_vec[i] = ret.second;
                 }
+            } else if (bipartite) {
+                index.SearchBipartiteGraphBatch(aligned_query_data, q_pts, k, L_pq, nullptr, 10, res.data(), res_d.data(),
+                                                cmps_vec.data(), hops_vec.data());
             } else {
                 index.SearchRoarGraphBatch(aligned_query_data, q_pts, k, L_pq, res.data(), res_d.data(),
                                            cmps_vec.data(), hops_vec.data());
@@ -212,6 +240,14 @@ int main(int argc, char **argv) {
             if (per_query)  // the per-query path fills res_dists[i]; flatten for the error metric
                 for (size_t i = 0; i < q_pts; ++i) std::copy(res_dists[i].begin(), res_dists[i].begin() + k, res_d.begin() + i * k);
             double rderr = want_rderr ? ComputeRderr(gt_dists, gt_dim, res_d.data(), q_pts, k, dist_metric) : 0.0;
+            if (bipartite) {  // column order of tests/test_search_bipartite.cpp:224-231
+                std::cout << L_pq << "\t\t" << qps << "\t\t" << (float)avg_cmps << "\t\t" << (float)(diff_ms / q_pts)
+                          << "\t\t" << recall << "\t\t" << rderr << "\t\t" << (float)avg_hops << std::endl;
+                if (evaluation_out.is_open())
+                    evaluation_out << L_pq << "," << qps << "," << (float)avg_cmps << "," << (float)(diff_ms / q_pts) << ","
+                                   << recall << "," << rderr << "," << (float)avg_hops << std::endl;
+                continue;
+            }
             std::cout << L_pq << "\t\t" << qps << "\t\t" << (float)avg_cmps << "\t\t" << (float)(diff_ms / q_pts) << "\t\t"
                       << recall << "\t\t" << (float)avg_hops;
             if (want_rderr) std::cout << "\t\t" << rderr;

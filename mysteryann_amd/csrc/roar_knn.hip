@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 namespace {
 
 typedef unsigned long long u64;
@@ -275,10 +277,21 @@ int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint
         p.first = 0; p.stride = stride; p.count = (n + stride - 1) / stride;
         p.tau = (const float *)tau; p.cand = (u64 *)cand; p.cursor = (uint32_t *)cursor; p.cap = cap; p.ip = ip;
         if ((e = hipMemsetAsync(cursor, 0, (size_t)nq * 4, st)) != hipSuccess) return (int)e;
-        dim3 grid((uint32_t)(((p.count + TB - 1) / TB) * ((nq + TQ - 1) / TQ)));
-        hipLaunchKernelGGL(knn_pass_kernel, grid, dim3(256), 0, st, p);
+        // a launch may not exceed 2^32 - 1 threads in x: split the sample of this pass into runs of base tiles
+        const uint64_t nqt = (nq + TQ - 1) / TQ;
+        const uint64_t total_tiles = ((n + stride - 1) / stride + TB - 1) / TB;
+        const uint64_t max_tiles = std::max<uint64_t>(1, (0xFFFFFFFFull / 256) / nqt);
+        for (uint64_t t0 = 0; t0 < total_tiles; t0 += max_tiles) {
+            const uint64_t s0 = t0 * TB;  // first sample index of this run
+            const uint64_t tiles = std::min(max_tiles, total_tiles - t0);
+            p.first = s0 * stride;
+            p.count = std::min<uint64_t>((n + stride - 1) / stride - s0, tiles * TB);
+            hipLaunchKernelGGL(knn_pass_kernel, dim3((uint32_t)(tiles * nqt)), dim3(256), 0, st, p);
+            if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        }
         hipLaunchKernelGGL(knn_select_kernel, dim3(nq), dim3(256), (size_t)cap * 8, st, (u64 *)cand, (uint32_t *)cursor, cap,
                            nq, k, (float *)tau, (uint32_t *)overflow_dev);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(knn_emit_kernel, dim3(nq), dim3(64), 0, st, (const u64 *)cand, (const uint32_t *)cursor, cap, nq, k,
                        q, (u64)ldq, dim, ip, ids, dists);

@@ -436,6 +436,30 @@ def test_exact_knn_generator_matches_brute_force(metric, d, k, built_lib):
         assert np.allclose(dists[qi], ref, rtol=1e-4, atol=1e-4 * scale[qi])
 
 
+def test_exact_knn_query_block_larger_than_one_launch(built_lib):
+    """65 536 queries x 4.3 M rows: (query tiles x base tiles x 256 threads) exceeds the 2^32 - 1 threads one
+    launch may have, so a pass is split into runs of base tiles.  The big call must equal 8 192-query calls
+    and a torch top-k on a sample."""
+    import torch
+
+    from mysteryann_amd import index as mi
+
+    n, d, nq, k = 4_300_000, 64, 65_536, 10
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn((n, d), device="cuda", generator=g)
+    q = torch.randn((nq, d), device="cuda", generator=g)
+    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    big, _ = idx.ExactKnnDevice(q, k, want_dists=False)
+    small = torch.cat([idx.ExactKnnDevice(q[a:a + 8192], k, want_dists=False)[0] for a in range(0, nq, 8192)])
+    torch.cuda.synchronize()
+    assert bool((big == small).all())
+    ref = torch.topk(q[-512:] @ base.T, k, dim=1).indices
+    same = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref.cpu(), big[-512:].cpu())) / (512 * k)
+    assert same > 0.999
+    idx.close()
+
+
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
     """Default policy: on-chip tag table below L_pq = 512, HBM epoch tags from there on; both give the
     reference's results."""

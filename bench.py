@@ -110,7 +110,9 @@ def main():
                     help="exact learn->base kNN lists (MFMA brute force) for the first N training queries")
     ap.add_argument("--torch-gt", action="store_true", help="ground truth by torch matmul+topk instead of the MFMA generator")
     ap.add_argument("--build-phase1-ip", action="store_true", help="phase 1 by the index metric instead of L2")
-    ap.add_argument("--learn", type=int, default=-1, help="training queries for the projection pass (-1 = n/2)")
+    ap.add_argument("--learn", type=int, default=-1,
+                    help="training queries for the projection pass (-1 = n, the reference's T2I-10M setting: as many "
+                         "training queries as base points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
@@ -142,7 +144,7 @@ def main():
     from mysteryann_amd import synth
 
     t0 = time.time()
-    n_learn = args.learn if args.learn >= 0 else max(args.n // 2, 1000)
+    n_learn = args.learn if args.learn >= 0 else args.n
     gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch}[args.workload]
     base, queries, learn = gen(args.n, args.nq, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
                                query_seed=args.seed + 2 + 1000 * rank)

@@ -20,6 +20,7 @@ ap.add_argument("--nq", type=int, default=10_000)
 ap.add_argument("--cpu-queries", type=int, default=1000)
 ap.add_argument("--M", type=int, default=35)
 ap.add_argument("--Ls", type=int, nargs="+", default=[10, 20, 50, 100, 200, 500, 1000])
+ap.add_argument("--visited", default="auto", choices=["auto", "exact", "lds"])
 ap.add_argument("--out", default="gpurun_out/bipartite_sweep.csv")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, args.nq, 10
@@ -35,6 +36,7 @@ par = mi.Parameters(); par.Set("M_pjbp", args.M)
 t0 = time.time(); idx.BuildBipartite(args.learn, None, n, None, par); t_build = time.time() - t0
 print(f"# exact learn->base lists {t_knn:.1f}s, qbaseNNbipartite + upload {t_build:.1f}s, "
       f"{idx.info('bipartite_nodes')} nodes {idx.info('bipartite_edges')} edges", flush=True)
+idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2}[args.visited])
 gt = idx.ExactKnnDevice(queries, k, want_dists=False)[0].to(torch.int64)
 impl = "ref" if oracle.have_ref() else "port"
 threads = min(oracle.max_threads(impl), bench.effective_cpus())

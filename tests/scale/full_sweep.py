@@ -17,7 +17,7 @@ ap.add_argument("--cpu-queries", type=int, default=2000)
 ap.add_argument("--out", default="gpurun_out/sweep_t2i10m.csv")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
-base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n // 2)
+base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n)
 idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
 t0 = time.time(); idx.BuildBootstrapGraph(learn=learn); torch.cuda.synchronize(); del learn
 print(f"index built in {time.time() - t0:.1f}s, avg degree {idx.info('nedges') / n:.1f}", flush=True)

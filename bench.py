@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="t2i", choices=["t2i", "webvid", "sift"],
                     help="t2i = the BASELINE metric's configuration (default); webvid / sift = the other configs' shapes")
-    ap.add_argument("--n", type=int, default=0, help="base points (default: 10 M t2i, 2.5 M webvid, 1 M sift)")
+    ap.add_argument("--n", "--base-points", dest="n", type=int, default=0, help="base points (default: 10 M t2i, 2.5 M webvid, 1 M sift)")
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--k", type=int, default=10)

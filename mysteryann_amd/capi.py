@@ -19,8 +19,8 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_SHORT = 0, -1, -2, -3, -4, -5
 SYMBOLS = [
     "roar_create", "roar_destroy", "roar_last_error", "roar_load_base_fbin", "roar_set_base",
     "roar_set_base_device", "roar_load_graph_file", "roar_set_graph_csr", "roar_save_graph_file",
-    "roar_get_graph_csr", "roar_build_graph", "roar_build_roargraph", "roar_search_batch", "roar_search_batch_device", "roar_distances",
-    "roar_exact_knn_device", "roar_exact_knn",
+    "roar_get_graph_csr", "roar_build_graph", "roar_build_roargraph", "roar_search_batch",
+    "roar_search_batch_device", "roar_distances", "roar_exact_knn_device", "roar_exact_knn",
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
     "roar_load_bipartite_file", "roar_save_bipartite_file", "roar_set_bipartite_csr", "roar_get_bipartite_csr",
     "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
@@ -33,7 +33,8 @@ class BuildParams(C.Structure):
     _fields_ = [("M", C.c_uint32), ("base_cap", C.c_uint32), ("max_degree", C.c_uint32), ("L_build", C.c_uint32),
                 ("max_batch", C.c_uint64), ("learn_dev", C.c_void_p), ("n_learn", C.c_uint64),
                 ("learn_stride_floats", C.c_uint32), ("M_sq", C.c_uint32), ("M_pj", C.c_uint32),
-                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("n_knn", C.c_uint64), ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
+                ("L_learn", C.c_uint32), ("rounds", C.c_uint32), ("phase1_l2", C.c_uint32), ("n_knn", C.c_uint64),
+                ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
                 ("L_learn_last", C.c_uint32), ("phase1_cand", C.c_uint32), ("supply_cand", C.c_uint32),
                 ("proj_mode", C.c_uint32), ("supply_mode", C.c_uint32), ("no_skeleton", C.c_uint32),
                 ("trim_min_proj", C.c_uint32), ("trim_keep_base", C.c_uint32)]
@@ -47,7 +48,8 @@ class RoarError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_knn.hip", "roar_capi.cpp", "roar_device.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_knn.hip", "roar_capi.cpp",
+                                             "roar_device.h")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

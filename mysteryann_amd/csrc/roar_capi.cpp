@@ -154,6 +154,7 @@ void free_base(roar_index *idx) {
     idx->base = nullptr;
     idx->base_owned = false;
     idx->n = 0;
+    idx->bp_checked = false;  // the bipartite split point is the number of base rows
 }
 
 void free_tags(roar_index *idx) {

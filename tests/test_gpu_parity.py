@@ -908,3 +908,61 @@ def test_bipartite_cli_pipeline_on_files(tmp_path, built_lib):
     assert abs(float(row[4]) - oracle.recall(r["ids"], gt_ids, 10)) < 1e-5
     assert abs(float(row[5]) - oracle.rderr(gt_d, r["dists"], 10, 1)) < 1e-6 * max(1.0, abs(float(row[5])))
     idx.close()
+
+
+def test_api_edges_empty_batch_call_order_and_limits(golden_dir, tmp_path, built_lib):
+    """Empty query block, calls out of order, a graph that does not match the base set, truncated files,
+    out-of-range ids, a pool that cannot fit on chip, k = L_pq = 1 and the smallest row (8 floats)."""
+    import oracle
+    from mysteryann_amd import index as mi
+    from mysteryann_amd.capi import ERR_ARG, ERR_FORMAT, RoarError
+
+    idx = mi.IndexBipartite(200, 0, 1, None)
+    q = np.zeros((3, 200), np.float32)
+    with pytest.raises(RoarError, match="before base vectors were loaded") as e:
+        idx.SearchRoarGraphBatch(q, 1, 1)
+    assert e.value.code == ERR_ARG
+    idx.LoadSearchNeededData(os.path.join(golden_dir, "ip_200.base.fbin"))
+    with pytest.raises(RoarError, match="before the projection graph was loaded"):
+        idx.SearchRoarGraphBatch(q, 1, 1)
+    with pytest.raises(RoarError, match="before the bipartite graph was loaded"):
+        idx.SearchBipartiteGraphBatch(q, 1, 1, np.zeros((3, 1), np.uint32))
+    idx.LoadProjectionGraph(os.path.join(golden_dir, "l2_128.roar.index"))  # 2000 nodes too: accepted
+    r = idx.SearchRoarGraphBatch(np.zeros((0, 200), np.float32), 10, 10)  # nq = 0 is a no-op
+    assert r["ids"].shape == (0, 10)
+    with pytest.raises(RoarError, match="bytes of LDS"):
+        idx.SearchRoarGraphBatch(q, 10, 30000)
+    with pytest.raises(RoarError, match="query stride smaller than the dimension"):
+        idx.SearchRoarGraphBatch(np.zeros((3, 64), np.float32), 1, 1)
+    # graph / base mismatch and malformed graphs
+    small = mi.IndexBipartite(8, 0, 0, None)
+    small.SetBaseData(np.eye(8, dtype=np.float32))
+    with pytest.raises(RoarError) as e:
+        small.SetProjectionGraph(9, np.zeros(9, np.uint64), np.zeros(0, np.uint32))  # entry point outside
+    assert e.value.code == ERR_FORMAT
+    with pytest.raises(RoarError) as e:
+        small.SetProjectionGraph(0, np.array([0, 1] + [1] * 7, np.uint64), np.array([8], np.uint32))  # neighbour outside
+    assert e.value.code == ERR_FORMAT
+    small.SetProjectionGraph(0, np.zeros(5, np.uint64), np.zeros(0, np.uint32))  # 4 nodes, base has 8 rows
+    with pytest.raises(RoarError, match="graph has 4 nodes but base has 8 rows"):
+        small.SearchRoarGraphBatch(np.ones((1, 8), np.float32), 1, 1)
+    trunc = str(tmp_path / "trunc.index")
+    open(trunc, "wb").write(open(os.path.join(golden_dir, "ip_200.roar.index"), "rb").read()[:1001 * 4])
+    with pytest.raises(RoarError, match="graph file truncated"):
+        small.LoadProjectionGraph(trunc)
+    with pytest.raises(RoarError, match="graph file truncated"):
+        small.Load(trunc)
+    # k = L_pq = 1 on the smallest row: a ring over the 8 unit vectors, the walk ends where the reference's does
+    off = np.arange(9, dtype=np.uint64)
+    nbrs = ((np.arange(8) + 1) % 8).astype(np.uint32)
+    small.SetProjectionGraph(3, off, nbrs)
+    qq = np.eye(8, dtype=np.float32)[[5, 0]] * 2
+    for mode in (0, 1):
+        small.set_option("visited_mode", mode)
+        for L in (1, 2, 8):
+            o = oracle.search_batch(np.eye(8, dtype=np.float32), off, nbrs, 3, qq, 1, L, 0)
+            r = small.SearchRoarGraphBatch(qq, 1, L)
+            for key in ("ids", "dists", "cmps", "hops"):
+                assert np.array_equal(r[key], o[key]), (mode, L, key)
+    idx.close()
+    small.close()

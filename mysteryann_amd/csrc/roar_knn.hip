@@ -118,8 +118,7 @@ __global__ void __launch_bounds__(256) knn_pass_kernel(const KnnPassParams p) {
         if (kc + 1 < nchunks) load_regs(kc + 1);  // in flight under the MFMAs of this chunk
         const float *aq = &sq[buf][(wr * 64 + (lane & 31)) * LDS_LD + (lane >> 5)];
         const float *ab = &sb[buf][(wc * 64 + (lane & 31)) * LDS_LD + (lane >> 5)];
-#pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
+        auto mfma_step = [&](int s) {
             const float a0 = aq[2 * s], a1 = aq[32 * LDS_LD + 2 * s];
             const float b0 = ab[2 * s], b1 = ab[32 * LDS_LD + 2 * s];
             // D = A(32 x 2, queries) * B(2 x 32, base rows) + C
@@ -127,6 +126,13 @@ __global__ void __launch_bounds__(256) knn_pass_kernel(const KnnPassParams p) {
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        };
+        const uint32_t kleft = p.dim - kc * KC;
+        if (kleft >= (uint32_t)KC) {
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) mfma_step(s);
+        } else {  // last chunk of a row length that is not a multiple of 32 (D = 200: 8 floats): skip the zero columns
+            for (int s = 0; s < (int)(kleft / 2); ++s) mfma_step(s);
         }
         if (kc + 1 < nchunks) write_lds(buf ^ 1);
         __syncthreads();

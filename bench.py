@@ -329,7 +329,11 @@ def main():
                      "avg_cmps": float(ex["cmps"].float().mean()), "avg_hops": float(ex["hops"].float().mean()),
                      "avg_scanned": float(ex["scanned"].float().mean()),
                      "lds_mode_cmps": float(out["cmps"].float().mean()), "grid": idx.info("last_grid"),
-                     "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids},
+                     "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids,
+                     # north_star asks for MFMA utilisation beside HBM GB/s: this kernel is GEMV shaped
+                     # (0.5 flop/B) and issues no MFMA; the repo's MFMA kernel is the exact-kNN generator
+                     # (knn_pass_kernel, 0.57 of the f32 peak, MFMA pipes 65 % busy: profiles/r01_counters.txt)
+                     "mfma_util": 0.0},
     }
 
     # HBM traffic per launch comes from a separate rocprofv3 --pmc capture of this same command

@@ -98,14 +98,6 @@ def main():
     ap.add_argument("--build-C3", type=int, default=48, help="supply candidates to prune from (0 = unpruned)")
     ap.add_argument("--build-projmode", type=int, default=0)
     ap.add_argument("--build-supplymode", type=int, default=0)
-    ap.add_argument("--two-stage", type=int, default=0,
-                    help="1: rebuild in the reference's shape (no skeleton) from lists searched on the first graph")
-    ap.add_argument("--stage2-L", type=int, default=128)
-    ap.add_argument("--stage2-Msq", type=int, default=48)
-    ap.add_argument("--stage2-Mpj", type=int, default=24)
-    ap.add_argument("--stage2-supply", type=int, default=24)
-    ap.add_argument("--stage2-supplyL", type=int, default=128)
-    ap.add_argument("--stage2-maxdeg", type=int, default=72)
     ap.add_argument("--build-trim", type=int, nargs=2, default=[8, 0], metavar=("MIN_PROJ", "KEEP_BASE"))
     ap.add_argument("--max-L", type=int, default=2000)
     ap.add_argument("--exact-knn", type=int, default=0,
@@ -173,20 +165,6 @@ def main():
                             phase1_cand=args.build_C1, supply_cand=args.build_C3, proj_mode=args.build_projmode,
                             supply_mode=args.build_supplymode)
     torch.cuda.synchronize()
-    if args.two_stage and n_learn:
-        t1 = time.time()
-        lists = torch.empty((n_learn, args.stage2_Msq), dtype=torch.int32, device=dev)
-        for a in range(0, n_learn, 1 << 19):
-            o = idx.SearchRoarGraphBatchDevice(learn[a:a + (1 << 19)], args.stage2_Msq, max(args.stage2_L, args.stage2_Msq))
-            lists[a:a + (1 << 19)] = o["ids"]
-        torch.cuda.synchronize()
-        log(f"[rank {rank}] stage 2: learn->base lists ({n_learn} x {args.stage2_Msq}) searched at L={args.stage2_L} in "
-            f"{time.time() - t1:.1f}s")
-        idx.BuildBootstrapGraph(no_skeleton=True, learn=None, learn_knn=lists, M_sq=args.stage2_Msq, M_pj=args.stage2_Mpj,
-                                rounds=0, supply_k=args.stage2_supply, supply_cand=max(48, args.stage2_supply),
-                                supply_L=args.stage2_supplyL, max_degree=args.stage2_maxdeg, trim_min_proj=0)
-        torch.cuda.synchronize()
-        del lists
     build_s = time.time() - t0
     log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
         f"max degree {idx.info('max_degree')}, ep {idx.info('ep')}")

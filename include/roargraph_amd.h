@@ -240,8 +240,12 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query
  *                    (latency form; auto picks it when the whole batch is resident that way)
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
+ *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
+ *                    threads while a launch is in flight share the next launch (the reference's harness calls
+ *                    SearchRoarGraph once per query from num_threads OpenMP threads,
+ *                    tests/test_search_roargraph.cpp:203-209); 0: one launch per call
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
- *   "bipartite_nodes", "bipartite_edges",
+ *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
  *   "row_stride", "last_grid", "last_lds_bytes", "last_vis_entries", "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */

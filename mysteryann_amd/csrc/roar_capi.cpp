@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -119,6 +120,23 @@ struct roar_index {
     // tests/test_search_roargraph.cpp:203); the host-buffer entry points share staging buffers, the
     // dequeue counter and the timing events, so concurrent callers are serialised here.
     std::mutex mu;
+    // single-query calls from concurrent host threads are combined into one launch (see search_one)
+    struct OneQuery {
+        const float *q;
+        uint32_t qstride, k, L;
+        uint32_t *ids;
+        float *dists;
+        uint32_t *cmps, *hops, *scanned;
+        int rc = 0;
+        std::string err;
+        bool done = false;
+    };
+    std::mutex cq_mu;
+    std::condition_variable cq_cv;
+    std::vector<OneQuery *> cq;
+    bool cq_leader = false;
+    int combine = 1;
+    int64_t last_combined = 0;
     // last launch
     int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
 };
@@ -928,12 +946,91 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
     return ROAR_OK;
 }
 
+namespace {
+int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
+                uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops, uint32_t *scanned);
+
+// The reference's harness calls SearchRoarGraph once per query from num_threads OpenMP threads
+// (tests/test_search_roargraph.cpp:203-209).  One-query launches would leave the GPU idle, so concurrent
+// one-query calls are combined: the first caller becomes the leader, gathers every request queued with the same
+// (k, L_pq) -- those that arrived while the previous launch was in flight -- runs them as one batch and hands
+// each caller its own rows; callers that find a leader wait for their result.  Results are those of the
+// batch path, i.e. of the reference, query by query.
+int search_one(roar_index *idx, roar_index::OneQuery &req) {
+    std::unique_lock<std::mutex> lk(idx->cq_mu);
+    idx->cq.push_back(&req);
+    if (idx->cq_leader) {
+        idx->cq_cv.wait(lk, [&] { return req.done; });
+    } else {
+        idx->cq_leader = true;
+        while (!idx->cq.empty()) {
+            std::vector<roar_index::OneQuery *> batch, rest;
+            const roar_index::OneQuery *head = idx->cq.front();
+            for (roar_index::OneQuery *r : idx->cq)
+                ((r->k == head->k && r->L == head->L && batch.size() < 4096) ? batch : rest).push_back(r);
+            idx->cq.swap(rest);
+            lk.unlock();
+            const uint64_t m = batch.size();
+            const uint32_t k = head->k, dp = idx->dim_pad;
+            std::vector<float> qbuf((size_t)m * dp, 0.0f);
+            for (uint64_t i = 0; i < m; ++i)
+                memcpy(&qbuf[i * dp], batch[i]->q, std::min(batch[i]->qstride, idx->dim) * sizeof(float));
+            std::vector<uint32_t> r_ids((size_t)m * k), r_cmps(m), r_hops(m), r_scan(m);
+            std::vector<float> r_d((size_t)m * k);
+            int rc = search_host(idx, qbuf.data(), m, dp, k, head->L, r_ids.data(), r_d.data(), r_cmps.data(), r_hops.data(),
+                                 r_scan.data());
+            const std::string err = g_err;
+            for (uint64_t i = 0; i < m; ++i) {
+                roar_index::OneQuery *r = batch[i];
+                r->rc = rc;
+                r->err = err;
+                if (rc == ROAR_OK || rc == ROAR_ERR_SHORT) {
+                    memcpy(r->ids, &r_ids[i * k], k * sizeof(uint32_t));
+                    memcpy(r->dists, &r_d[i * k], k * sizeof(float));
+                    if (r->cmps) *r->cmps = r_cmps[i];
+                    if (r->hops) *r->hops = r_hops[i];
+                    if (r->scanned) *r->scanned = r_scan[i];
+                    uint32_t have = 0;
+                    while (have < k && r_ids[i * k + have] != 0xFFFFFFFFu) have++;
+                    r->rc = ROAR_OK;
+                    if (have < k) {  // this query's own shortfall, worded as the reference throws it (:2408-2412)
+                        char msg[96];
+                        snprintf(msg, sizeof msg, "not enough results: %u, expected: %u", have, k);
+                        r->rc = ROAR_ERR_SHORT;
+                        r->err = msg;
+                    }
+                }
+            }
+            lk.lock();
+            idx->last_combined = (int64_t)m;
+            for (roar_index::OneQuery *r : batch) r->done = true;
+            idx->cq_cv.notify_all();
+        }
+        idx->cq_leader = false;
+    }
+    if (req.rc != ROAR_OK) g_err = req.err;
+    return req.rc;
+}
+}  // namespace
+
 int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                       uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
                       uint32_t *scanned) {
     if (!idx || !ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    if (nq == 1 && idx->combine && k > 0 && k <= 4096) {
+        roar_index::OneQuery req;
+        req.q = queries, req.qstride = qstride_floats, req.k = k, req.L = L_pq;
+        req.ids = ids, req.dists = dists, req.cmps = cmps, req.hops = hops, req.scanned = scanned;
+        return search_one(idx, req);
+    }
+    return search_host(idx, queries, nq, qstride_floats, k, L_pq, ids, dists, cmps, hops, scanned);
+}
+
+namespace {
+int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
+                uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops, uint32_t *scanned) {
     std::lock_guard<std::mutex> guard(idx->mu);
     int e = use_device(idx);
     if (e) return e;
@@ -950,6 +1047,7 @@ int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32
     HIP_TRY(hipDeviceSynchronize());
     return fetch_results(idx, nq, k, ids, dists, cmps, hops, scanned);
 }
+}  // namespace
 
 
 // ---- bipartite two-hop variant -------------------------------------------------
@@ -1359,6 +1457,8 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "search_kernel") {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1 or 2");
         idx->search_kernel = (int)value;
+    } else if (k == "combine_single_queries") {
+        idx->combine = value ? 1 : 0;
     } else if (k == "bipartite_seed") {
         idx->bp_seed = (uint64_t)value;
     } else if (k == "max_grid") {
@@ -1386,6 +1486,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
     else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : 1;
+    else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;
     else if (k == "last_grid") *value = idx->last_grid;

@@ -966,3 +966,54 @@ def test_api_edges_empty_batch_call_order_and_limits(golden_dir, tmp_path, built
                 assert np.array_equal(r[key], o[key]), (mode, L, key)
     idx.close()
     small.close()
+
+
+def test_concurrent_single_query_calls_are_combined(golden_dir, built_lib):
+    """The reference's harness shape: SearchRoarGraph once per query from many host threads
+    (tests/test_search_roargraph.cpp:203-209).  Concurrent one-query calls are combined into one launch; every
+    caller must still get exactly its own query's reference result, mixed (k, L_pq) included."""
+    import threading
+
+    from mysteryann_amd import index as mi
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.expected.npz"))
+    idx, q = _index("ip_200", golden_dir, 0)
+    nq = q.shape[0]
+    got = {L: dict(ids=np.zeros((nq, K), np.uint32), dists=np.zeros((nq, K), np.float32), cmps=np.zeros(nq, np.uint32),
+                   hops=np.zeros(nq, np.uint32)) for L in (20, 50)}
+    combined = []
+    errors = []
+
+    def worker(t, nthreads):
+        try:
+            for rep in range(3):
+                for i in range(t, nq, nthreads):
+                    L = 20 if (i + rep) % 2 else 50
+                    par = mi.Parameters()
+                    par.Set("L_pq", L)
+                    ind, dd = np.zeros(K, np.uint32), np.zeros(K, np.float32)
+                    c, h = idx.SearchRoarGraph(q[i], K, i, par, ind, dd)
+                    g = got[L]
+                    g["ids"][i], g["dists"][i], g["cmps"][i], g["hops"][i] = ind, dd, c, h
+                    combined.append(idx.info("last_combined"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t, 16)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for L in (20, 50):
+        for key in ("ids", "dists", "cmps", "hops"):
+            assert np.array_equal(got[L][key], exp[f"{key}_{L}"]), (L, key)
+    assert max(combined) > 1  # at least one launch carried several callers' queries
+    # switched off: one launch per call, same results
+    idx.set_option("combine_single_queries", 0)
+    par = mi.Parameters()
+    par.Set("L_pq", 50)
+    ind, dd = np.zeros(K, np.uint32), np.zeros(K, np.float32)
+    c, h = idx.SearchRoarGraph(q[3], K, 3, par, ind, dd)
+    assert np.array_equal(ind, exp["ids_50"][3]) and (c, h) == (int(exp["cmps_50"][3]), int(exp["hops_50"][3]))
+    idx.close()

@@ -407,13 +407,26 @@ int fetch_results(roar_index *idx, uint64_t nq, uint32_t k, uint32_t *ids, float
     uint32_t *d_hops = d_cmps + nq;
     uint32_t *d_scan = d_hops + nq;
     uint32_t *d_short = d_scan + nq;
-    HIP_TRY(hipMemcpy(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dists, d_dists, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    if (cmps) HIP_TRY(hipMemcpy(cmps, d_cmps, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    if (hops) HIP_TRY(hipMemcpy(hops, d_hops, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    if (scanned) HIP_TRY(hipMemcpy(scanned, d_scan, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    // small batches (the combined one-query calls): one copy of the whole result block instead of six
     uint32_t nshort = 0;
-    HIP_TRY(hipMemcpy(&nshort, d_short, 4, hipMemcpyDeviceToHost));
+    const uint64_t words = nq * (2ull * k + 3) + 1;
+    if (words <= (1u << 16)) {
+        std::vector<uint32_t> blk((size_t)words);
+        HIP_TRY(hipMemcpy(blk.data(), d_ids, (size_t)words * 4, hipMemcpyDeviceToHost));
+        memcpy(ids, blk.data(), (size_t)nq * k * 4);
+        memcpy(dists, blk.data() + nq * k, (size_t)nq * k * 4);
+        if (cmps) memcpy(cmps, blk.data() + 2 * nq * k, (size_t)nq * 4);
+        if (hops) memcpy(hops, blk.data() + 2 * nq * k + nq, (size_t)nq * 4);
+        if (scanned) memcpy(scanned, blk.data() + 2 * nq * k + 2 * nq, (size_t)nq * 4);
+        nshort = blk[(size_t)words - 1];
+    } else {
+        HIP_TRY(hipMemcpy(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dists, d_dists, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+        if (cmps) HIP_TRY(hipMemcpy(cmps, d_cmps, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        if (hops) HIP_TRY(hipMemcpy(hops, d_hops, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        if (scanned) HIP_TRY(hipMemcpy(scanned, d_scan, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&nshort, d_short, 4, hipMemcpyDeviceToHost));
+    }
     if (nshort) {
         // message of the first short query, as the reference would have thrown it (:2408-2412)
         for (uint64_t i = 0; i < nq; ++i) {

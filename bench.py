@@ -310,7 +310,7 @@ def main():
                      "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids,
                      # north_star asks for MFMA utilisation beside HBM GB/s: this kernel is GEMV shaped
                      # (0.5 flop/B) and issues no MFMA; the repo's MFMA kernel is the exact-kNN generator
-                     # (knn_pass_kernel, 0.57 of the f32 peak, MFMA pipes 65 % busy: profiles/r01_counters.txt)
+                     # (knn_pass_kernel, 0.57 of the f32 peak, MFMA pipes 60 % busy: profiles/r01_counters.txt)
                      "mfma_util": 0.0},
     }
 

@@ -3,7 +3,7 @@
 # L2 hit rate, LDS conflicts; MFMA busy share of the exact-kNN kernel.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r1c; mkdir -p $O; cd $R; export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --L 75"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --L 30"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq -- python3 $R/bench.py $ARGS > $O/sq.json 2> $O/sq.err; echo "sq rc=$?"
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $O/tcc -- python3 $R/bench.py $ARGS > $O/tcc.json 2> $O/tcc.err; echo "tcc rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/knn -- python3 $R/scripts/knn_bench.py > $O/knn.txt 2> $O/knn.err; echo "knn rc=$?"; cat $O/knn.txt

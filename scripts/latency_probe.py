@@ -3,9 +3,9 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mysteryann_amd import index as mi, synth
-n, d, L = 10_000_000, 200, 75
-base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n // 4)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base); idx.BuildBootstrapGraph(learn=learn); del learn
+n, d, L = 10_000_000, 200, 30  # bench.py's default graph and operating point
+base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n)
+idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base); idx.BuildBootstrapGraph(learn=learn, max_degree=200); del learn
 for nq in (1, 16, 64, 256, 1000, 2000, 2500, 4000, 10000):
     row = [f"nq={nq:6d}"]
     for kern in (1, 2):

@@ -1017,3 +1017,50 @@ def test_concurrent_single_query_calls_are_combined(golden_dir, built_lib):
     c, h = idx.SearchRoarGraph(q[3], K, 3, par, ind, dd)
     assert np.array_equal(ind, exp["ids_50"][3]) and (c, h) == (int(exp["cmps_50"][3]), int(exp["hops_50"][3]))
     idx.close()
+
+
+def test_combined_calls_keep_their_own_errors(built_lib):
+    """Callers that share a launch still fail or succeed on their own: k = 10 comes up short on a 3-node component
+    ('not enough results: 3, expected: 10', index_bipartite.cpp:2408-2412) while concurrent k = 3 callers succeed."""
+    import threading
+
+    from mysteryann_amd import index as mi
+    from mysteryann_amd.capi import ERR_SHORT
+
+    n, d = 64, 16
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = 2  # only node 0 has (two) neighbours
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(0, off, np.array([1, 2], np.uint32))
+    want = idx.SearchRoarGraphBatch(base[:8], 3, 20)
+    res = {}
+
+    def worker(t):
+        par = mi.Parameters()
+        par.Set("L_pq", 20)
+        out = []
+        for rep in range(20):
+            k = 10 if t % 2 else 3
+            ind, dd = np.zeros(k, np.uint32), np.zeros(k, np.float32)
+            try:
+                idx.SearchRoarGraph(base[t], k, t, par, ind, dd)
+                out.append(("ok", ind.copy()))
+            except mi.RoarError as e:
+                out.append((e.code, str(e)))
+        res[t] = out
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for t in range(8):
+        for tag, val in res[t]:
+            if t % 2:
+                assert tag == ERR_SHORT and val == "not enough results: 3, expected: 10", (t, tag, val)
+            else:
+                assert tag == "ok" and np.array_equal(val, want["ids"][t]), (t, tag, val)
+    idx.close()

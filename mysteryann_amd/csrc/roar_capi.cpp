@@ -281,8 +281,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
     const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;
     // (the two-hop walk touches an order of magnitude more distinct nodes per hop: the 8192-tag table forgets
-    // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 2.15 / 4.70 / 9.40 ms
-    // vs LDS 3.40 / 7.97 / 18.5 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
+    // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
+    // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
     const int mode = idx->visited_mode == ROAR_VISITED_AUTO
                          ? ((L < 512 && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                          : idx->visited_mode;

@@ -94,6 +94,10 @@ struct roar_index {
     std::vector<uint32_t> hb_nbrs;
     uint32_t *init_dev = nullptr;
     uint64_t init_cap = 0;
+    uint32_t *tags32 = nullptr;   // eight-waves-per-query form: u32 epoch tags, one list per resident workgroup
+    uint32_t *epochs32 = nullptr;
+    uint32_t slots32 = 0;
+    uint64_t tag_stride32 = 0;
     uint64_t bp_seed = 0x9E3779B97F4A7C15ull;
     // options
     int visited_mode = ROAR_VISITED_AUTO;
@@ -176,6 +180,11 @@ void free_base(roar_index *idx) {
 }
 
 void free_tags(roar_index *idx) {
+    if (idx->tags32) (void)hipFree(idx->tags32);
+    if (idx->epochs32) (void)hipFree(idx->epochs32);
+    idx->tags32 = nullptr;
+    idx->epochs32 = nullptr;
+    idx->slots32 = 0;
     if (idx->tags) (void)hipFree(idx->tags);
     if (idx->epochs) (void)hipFree(idx->epochs);
     idx->tags = nullptr;
@@ -217,6 +226,22 @@ int ensure_tags(roar_index *idx, uint32_t slots) {
     HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->epochs, 0, (size_t)slots * sizeof(uint32_t)));
     idx->slots = slots;
+    return ROAR_OK;
+}
+
+int ensure_tags32(roar_index *idx, uint32_t slots) {
+    if (idx->tags32 && idx->slots32 >= slots) return ROAR_OK;
+    if (idx->tags32) (void)hipFree(idx->tags32);
+    if (idx->epochs32) (void)hipFree(idx->epochs32);
+    idx->tags32 = nullptr;
+    idx->epochs32 = nullptr;
+    idx->slots32 = 0;
+    idx->tag_stride32 = ((idx->n + 3) / 4) * 4;
+    HIP_TRY(hipMalloc((void **)&idx->tags32, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->tags32, 0, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&idx->epochs32, (size_t)slots * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->epochs32, 0, (size_t)slots * sizeof(uint32_t)));
+    idx->slots32 = slots;
     return ROAR_OK;
 }
 
@@ -286,6 +311,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     const int mode = idx->visited_mode == ROAR_VISITED_AUTO
                          ? ((L < 512 && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                          : idx->visited_mode;
+    // bipartite, AUTO: eight waves per query while the pool is short (work per query is far too uneven for one
+    // wave each: T2I-10M, 10 000 queries, 14.0 / 20.0 / 32.8 / 44.9 / 68.2 ms at L_pq = 10 / 20 / 50 / 100 / 200 against
+    // 20.7 / 26.4 / 39.4 / 46.0 / 68.0 ms with one wave; from L_pq = 500 the waves queue for the shared pool and the
+    // one-wave form wins, 99 vs 113 ms); an explicit visited_mode keeps the one-wave form with that mode
+    const bool bp_wg = bipartite && idx->visited_mode == ROAR_VISITED_AUTO && L <= 200;
     idx->last_mode = mode;
     // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
     uint32_t sets_log2 = 0;
@@ -308,15 +338,15 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
     p.off_ck = off;
-    off += 8 * 128;
+    off += bp_wg ? 8 * 64 * 8 : 8 * 128;   // eight waves x 64 keys in the workgroup form
     p.off_cid = off;
-    off += 4 * 128;
+    off += bp_wg ? 4 * 64 * 8 : 4 * 128;
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
     p.off_vis = off;
     off += 2 * entries;
     p.off_ctrl = off;
-    off += 16;
+    off += bp_wg ? 64 : 16;
     if (bipartite) {
         p.off_bp = off;
         off += 768;
@@ -329,8 +359,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // one wave per query otherwise (throughput form)
     int occ = 0, mw = 0;
     if (bipartite) {
-        mw = 2;
-        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 2, idx->dim_pad, p.lds_bytes, &occ);
+        mw = bp_wg ? 3 : 2;
+        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, mw, idx->dim_pad, p.lds_bytes, &occ);
         if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
     } else if (idx->search_kernel != 1) {
         int occ_mw = 0;
@@ -353,7 +383,15 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;
     if (grid == 0) grid = 1;
     plan->grid = (uint32_t)grid;
-    if (mode == ROAR_VISITED_EXACT) {
+    if (bp_wg) {
+        // u32 tags: 4 n bytes per resident workgroup; 256 workgroups keep every CU busy with eight waves each
+        if (plan->grid > 256) plan->grid = 256;
+        int e = ensure_tags32(idx, std::max<uint32_t>(plan->grid, idx->slots32));
+        if (e) return e;
+        p.tags32 = idx->tags32;
+        p.tag_stride32 = idx->tag_stride32;
+        p.epochs = idx->epochs32;
+    } else if (mode == ROAR_VISITED_EXACT) {
         int e = ensure_tags(idx, std::max<uint32_t>(plan->grid, idx->slots));
         if (e) return e;
         p.tags = idx->tags;
@@ -1261,7 +1299,7 @@ int roar_search_bipartite_batch_device(roar_index *idx, const float *queries_dev
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, 2, plan.grid, st);
+    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, idx->last_mw, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -1498,7 +1536,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
-    else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : 1;
+    else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : idx->last_mw == 3 ? 8 : 1;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

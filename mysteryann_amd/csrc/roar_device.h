@@ -43,6 +43,9 @@ struct RoarSearchParams {
     const uint32_t *init_ids;
     uint32_t n_init;
     uint32_t off_bp;
+    // eight-waves-per-query form: one u32[tag_stride32] epoch list per resident workgroup (test-and-set)
+    uint32_t *tags32;
+    uint64_t tag_stride32;
 };
 
 struct RoarDistParams {
@@ -63,7 +66,7 @@ extern "C" {
 #endif
 // Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
 // visited_mode: 0 exact tags, 1 LDS table.  multi_wave: 0 one wave per query, 1 four waves per query,
-// 2 bipartite two-hop walk (one wave per query).  Returns a hipError_t value (0 = success).
+// 2 bipartite two-hop walk (one wave per query), 3 bipartite two-hop walk (eight waves per query).  Returns a hipError_t value (0 = success).
 int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave, uint32_t grid,
                        void *stream);
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);

@@ -744,6 +744,204 @@ __global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchP
     if (MODE == VIS_EXACT && lane == 0) p.epochs[blockIdx.x] = epoch;
 }
 
+// Workgroup form of the two-hop walk: 8 waves (512 threads) per query.  Work per query is extremely uneven
+// on a bipartite graph (most random entry points are dead ends, a hub hop has tens of thousands of two-hop
+// candidates), so a launch of the one-wave form lasts as long as its single heaviest query.  Here the eight
+// waves split every block of 512 flattened candidates: each wave filters its 64 entries with an exact
+// test-and-set on u32 epoch tags in HBM (atomicExch: no entry is taken twice, within or across waves, so cmps
+// equals the reference's), scores its survivors, drops those a full pool would reject (neighbor.h:151-153) and
+// only then takes its turn at the shared pool; wave 0 selects the next node and sets up the row extents.
+// Same results as roar_bipartite_kernel by the same argument (within a hop the pool is order-free).
+constexpr int BPW = 8;  // waves per query
+template <bool IP, int NCH>
+__global__ void __launch_bounds__(64 * BPW) roar_bipartite_kernel_wg(const RoarSearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck) + 64 * wid;
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid) + 64 * wid;
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    u64 *rstart = reinterpret_cast<u64 *>(smem + p.off_bp);
+    uint32_t *rpre = reinterpret_cast<uint32_t *>(smem + p.off_bp + 512);
+    // ctrl: 0 query, 1 psize, 2 cur, 3 cmps, 4 merge mask, 5 node being expanded, 6 "has node", 7 row total
+    volatile uint32_t *ctrl = reinterpret_cast<volatile uint32_t *>(smem + p.off_ctrl);
+    uint32_t *ctrl_a = reinterpret_cast<uint32_t *>(smem + p.off_ctrl);
+    const uint32_t L = p.L;
+    uint32_t *tags = p.tags32 + (u64)blockIdx.x * p.tag_stride32;
+    uint32_t epoch = p.epochs[blockIdx.x];
+
+    for (;;) {
+        if (threadIdx.x == 0) ctrl[0] = atomicAdd(p.counter, 1u);
+        __syncthreads();
+        const uint32_t q = ctrl[0];
+        if (q >= p.nq) break;
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * BPW)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        epoch++;
+        if (epoch == 0u) {  // VisitedList::reset wrap (visited_list_pool.h:20-26)
+            for (u64 i = threadIdx.x; i < p.tag_stride32; i += 64 * BPW) tags[i] = 0u;
+            __threadfence();
+            epoch = 1;
+        }
+        __syncthreads();
+        if (wid == 0) {  // entry points (:304-316): scored, inserted, marked; not counted
+            const bool isinit = (uint32_t)lane < p.n_init;
+            const uint32_t iid = isinit ? p.init_ids[(u64)q * p.n_init + lane] : 0u;
+            if (isinit) cid[lane] = iid;
+            wave_sync();
+            score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, p.n_init, lane);
+            wave_sync();
+            if (lane == 0) pool[0] = ck[0];
+            wave_sync();
+            uint32_t psize = 1, cur = 0;
+            merge_candidates(pool, ck, p.n_init, L, psize, cur, lane);
+            if (isinit) (void)atomicExch(&tags[iid], epoch);
+            if (lane == 0) {
+                ctrl[1] = psize;
+                ctrl[2] = cur;
+                ctrl[3] = 0;
+                ctrl[4] = 0;
+            }
+        }
+        __syncthreads();
+        uint32_t hops = 0, scanned = 0;
+        for (;;) {
+            if (wid == 0) {  // closest_unexpanded (neighbor.h:185-192)
+                const uint32_t psize = ctrl[1];
+                uint32_t cur = ctrl[2];
+                if (cur < psize) {
+                    const u64 e = pool[cur];
+                    if (lane == 0) pool[cur] = e | 1ull;
+                    wave_sync();
+                    uint32_t found = psize;
+                    for (uint32_t c = cur + 1; c < psize; c += 64) {
+                        const uint32_t kidx = c + (uint32_t)lane;
+                        const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                        const u64 b = __ballot(unf);
+                        if (b) {
+                            found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                            break;
+                        }
+                    }
+                    if (lane == 0) {
+                        ctrl[2] = found;
+                        ctrl[5] = (uint32_t)e >> 1;
+                        ctrl[6] = 1;
+                    }
+                } else if (lane == 0) {
+                    ctrl[6] = 0;
+                }
+            }
+            __syncthreads();
+            if (!ctrl[6]) break;
+            const uint32_t v = ctrl[5];
+            ++hops;
+            const u64 b0 = p.bp_off[v], b1 = p.bp_off[v + 1];
+            scanned += (uint32_t)(b1 - b0);
+            for (u64 r = b0; r < b1; r += 64) {
+                if (wid == 0) {  // row extents of the next 64 query nodes
+                    const bool hasq = r + (u64)lane < b1;
+                    u64 s0 = 0;
+                    uint32_t len = 0;
+                    if (hasq) {
+                        const uint32_t qn = p.bp_nbrs[r + lane];
+                        s0 = p.bp_off[qn];
+                        len = (uint32_t)(p.bp_off[qn + 1] - s0);
+                    }
+                    uint32_t incl = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t y = __shfl_up(incl, d);
+                        if (lane >= d) incl += y;
+                    }
+                    rstart[lane] = s0;
+                    rpre[lane] = incl - len;
+                    if (lane == 63) ctrl[7] = incl;
+                }
+                __syncthreads();
+                const uint32_t total = ctrl[7];
+                scanned += total;
+                for (uint32_t c0 = 0; c0 < total; c0 += 64 * BPW) {
+                    const uint32_t c = c0 + 64u * (uint32_t)wid + (uint32_t)lane;
+                    const bool has = c < total;
+                    uint32_t own = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1)
+                        if (rpre[own + step] <= c) own += step;
+                    uint32_t nb = 0;
+                    bool fresh = false;
+                    if (has) {
+                        nb = p.bp_nbrs[rstart[own] + (c - rpre[own])];
+                        fresh = atomicExch(&tags[nb], epoch) != epoch;  // :330-334, exact across lanes and waves
+                    }
+                    const u64 fm = __ballot(fresh);
+                    const uint32_t m = (uint32_t)__popcll(fm);
+                    bool want = false;
+                    if (m) {
+                        if (fresh) cid[lanes_below(fm)] = nb;
+                        wave_sync();
+                        score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid, ck, m, lane);
+                        wave_sync();
+                        // a full pool rejects what is not better than its last entry (neighbor.h:151-153); the
+                        // pool cannot change between the two barriers around this block
+                        const bool mine = (uint32_t)lane < m;
+                        const u64 key = mine ? ck[lane] : ~0ull;
+                        const bool ok = mine && (ctrl[1] < L || key < (pool[L - 1] & ~1ull));
+                        want = __ballot(ok) != 0;
+                        if (lane == 0) {
+                            atomicAdd(&ctrl_a[3], m);  // ++cmps, :342
+                            if (want) atomicOr(&ctrl_a[4], 1u << wid);
+                        }
+                    }
+                    __syncthreads();
+                    uint32_t mask = ctrl[4];
+                    __syncthreads();
+                    if (threadIdx.x == 0) ctrl[4] = 0;
+                    while (mask) {  // the waves that have something to insert take turns at the pool
+                        const int w = __ffs((int)mask) - 1;
+                        mask &= mask - 1;
+                        if (wid == w) {
+                            uint32_t psize = ctrl[1], cur = ctrl[2];
+                            merge_candidates(pool, ck, m, L, psize, cur, lane);
+                            if (lane == 0) {
+                                ctrl[1] = psize;
+                                ctrl[2] = cur;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    __syncthreads();  // the mask reset is in place before the next round's atomicOr
+                }
+                __syncthreads();  // rstart / rpre are rewritten by the next 64 query nodes
+            }
+            __syncthreads();  // ctrl[5], ctrl[6] are rewritten by the next select (a hop over an empty row has no other barrier)
+        }
+        if (wid == 0) {
+            const uint32_t psize = ctrl[1];
+            for (uint32_t i = lane; i < p.k; i += 64) {
+                uint32_t id = 0xFFFFFFFFu;
+                float d = __builtin_inff();
+                if (i < psize) {
+                    const u64 e = pool[i];
+                    id = (uint32_t)e >> 1;
+                    d = ord2f((uint32_t)(e >> 32));
+                }
+                p.out_ids[(u64)q * p.k + i] = id;
+                p.out_dists[(u64)q * p.k + i] = d;
+            }
+            if (lane == 0) {
+                if (p.out_cmps) p.out_cmps[q] = ctrl[3];
+                if (p.out_hops) p.out_hops[q] = hops;
+                if (p.out_scanned) p.out_scanned[q] = scanned;
+                if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
+}
+
 // distance-only kernel: one wave per query, m explicit ids each (parity surface for A2/A3)
 template <bool IP>
 __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams p) {
@@ -807,6 +1005,13 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 
 template <int MODE, bool IP>
 const void *pick_nch(uint32_t dim, int mw) {
+    if (mw == 3) {  // bipartite two-hop walk, eight waves per query (visited: u32 epoch tags, test-and-set)
+        switch (dim >> 4) {
+            case 8: return (const void *)roar_bipartite_kernel_wg<IP, 8>;
+            case 12: return (const void *)roar_bipartite_kernel_wg<IP, 12>;
+            default: return (const void *)roar_bipartite_kernel_wg<IP, 0>;
+        }
+    }
     if (mw == 2) {  // bipartite two-hop walk
         switch (dim >> 4) {
             case 8: return (const void *)roar_bipartite_kernel<MODE, IP, 8>;
@@ -841,7 +1046,7 @@ extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int 
     }
     RoarSearchParams params = *p;
     void *args[] = {&params};
-    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave == 1 ? 256 : 64), args, p->lds_bytes, (hipStream_t)stream);
+    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave == 1 ? 256 : multi_wave == 3 ? 64 * BPW : 64), args, p->lds_bytes, (hipStream_t)stream);
 }
 
 extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
@@ -851,7 +1056,8 @@ extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave == 1 ? 256 : 64, lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave == 1 ? 256 : multi_wave == 3 ? 64 * BPW : 64,
+                                                             lds_bytes);
 }
 
 extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {

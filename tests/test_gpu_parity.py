@@ -697,7 +697,7 @@ def test_cli_pipeline_from_fbin_files_only(tmp_path, built_lib):
 
 # ---- bipartite two-hop variant: SearchBipartiteGraph (index_bipartite.cpp:282-356), SURVEY 8(f) row 4 ----
 @pytest.mark.parametrize("case,metric", [("ip_200", 1), ("l2_128", 0)])
-@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["exact", "lds", "auto-8-waves"])
 def test_bipartite_search_matches_reference_golden(case, metric, mode, golden_dir, tmp_path, built_lib):
     from mysteryann_amd import fileio
     from mysteryann_amd import index as mi
@@ -732,7 +732,7 @@ def test_bipartite_random_graphs_against_oracle(metric, built_lib):
     base = rng.standard_normal((nb, d)).astype(np.float32)
     q = rng.standard_normal((96, d)).astype(np.float32)
     off, nbrs = _random_bipartite(rng, nb, nl, max_q=8, max_b=40, hub=11)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):  # 2 = AUTO: the eight-waves-per-query form with test-and-set tags
         idx = mi.IndexBipartite(d, nb, metric, None)
         idx.SetBaseData(base)
         idx.SetBipartiteGraph(off, nbrs)
@@ -753,8 +753,9 @@ def test_bipartite_random_graphs_against_oracle(metric, built_lib):
                 r = idx.SearchBipartiteGraphBatch(q, 5, L, init)
                 for key in ("ids", "dists", "hops"):
                     assert np.array_equal(r[key], o[key]), (mode, n_init, L, key)
-                if mode == 0:
-                    assert np.array_equal(r["cmps"], o["cmps"]), (n_init, L)
+                assert idx.info("last_waves_per_query") == (8 if mode == 2 and L <= 200 else 1)
+                if mode != 1:
+                    assert np.array_equal(r["cmps"], o["cmps"]), (mode, n_init, L)
                 else:
                     assert (r["cmps"] >= o["cmps"]).all()
         idx.close()

@@ -190,7 +190,9 @@ int roar_bipartite_entry_ids(uint64_t seed, uint64_t nq, uint32_t n_init, uint64
  * tests/test_search_bipartite.cpp:194-201, batched.  Every entry point is scored, inserted and marked
  * visited (not counted in cmps); an expansion scores the not-yet-visited base nodes two hops away
  * (first occurrence wins); hops counts expansions, including those of nodes with an empty row.
- * Errors as roar_search_batch ("not enough results: x, expected: k" -> ROAR_ERR_SHORT). */
+ * Errors as roar_search_batch ("not enough results: x, expected: k" -> ROAR_ERR_SHORT).
+ * With "visited_mode" AUTO a query is run by eight waves up to L_pq = 200 (work per query is very uneven on this
+ * graph), by one wave beyond; an explicit visited_mode keeps the one-wave form.  Results do not depend on it. */
 int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats,
                                 uint32_t k, uint32_t L_pq, const uint32_t *init_ids, uint32_t n_init, uint32_t *ids,
                                 float *dists, uint32_t *cmps, uint32_t *hops);

@@ -128,6 +128,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
     torch.cuda.set_device(local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     if use_dist:
         import torch.distributed as dist
 

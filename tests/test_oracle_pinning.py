@@ -178,6 +178,9 @@ def test_bipartite_restatement_matches_reference_golden(case, metric, golden_dir
         assert r["short"] == 0
         for key in ("ids", "dists", "cmps", "hops"):
             assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, L, key)
+    if case == "ip_200":  # with as many training queries as base points the two-hop walk does find the neighbours
+        gt, _ = fileio.read_gt(os.path.join(golden_dir, case + ".gt.ibin"))
+        assert oracle.recall(exp["ids_100"], gt, 10) > 0.9
     out = str(tmp_path / "b.index")  # IndexBipartite::Save format round trip
     oracle.bipartite_save(out, off, nbrs)
     assert open(src, "rb").read() == open(out, "rb").read()

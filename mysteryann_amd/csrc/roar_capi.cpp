@@ -106,6 +106,7 @@ struct roar_index {
     int vis_entries = 0;
     int max_grid = 0;
     int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query
+    bool building = false;  // searches issued by roar_build_graph run under their own kernel symbol
     int last_mw = 0;
     // workspaces
     uint32_t *counters = nullptr;  // [0] dequeue counter, [1] short count
@@ -375,6 +376,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 0, idx->dim_pad, p.lds_bytes, &occ);
         if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
     }
+    if (!mw && idx->building && mode == ROAR_VISITED_LDS) mw = 4;
     idx->last_mw = mw;
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
@@ -787,6 +789,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         (void)hipFree(res_ids); (void)hipFree(res_d); (void)hipFree(indeg); (void)hipFree(sums); (void)hipFree(scratch);
         (void)hipFree(base_deg);
         idx->visited_mode = saved_mode;
+        idx->building = false;
         idx->ip = idx->metric != ROAR_METRIC_L2;
     };
 #define BK_TRY(call)                                                                        \
@@ -805,6 +808,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     const uint32_t seed = (uint32_t)std::min<uint64_t>(n, 1024);
     if (!bp->no_skeleton) BK_TRY(roar_bk_seed(idx->adj, S, seed, idx->ep, std::min<uint32_t>(M, seed - 1), nullptr));
     idx->visited_mode = ROAR_VISITED_LDS;
+    idx->building = true;
     const bool saved_ip = idx->ip;
     auto search = [&](const float *q, uint64_t cnt, uint32_t qs, uint32_t k, uint32_t L) -> int {
         return roar_search_batch_device(idx, q, cnt, qs, k, L, res_ids, res_d, nullptr, nullptr, nullptr, nullptr, nullptr);

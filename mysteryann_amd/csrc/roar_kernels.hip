@@ -324,7 +324,7 @@ __device__ __forceinline__ bool visited_filter(bool isnbr, uint32_t nb, uint16_t
 
 
 template <int MODE, bool IP, int NCH>
-__global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchParams p) {
+__device__ __forceinline__ void search_one_wave(const RoarSearchParams &p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
@@ -432,6 +432,18 @@ __global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchPara
         wave_sync();
     }
     if (MODE == VIS_EXACT && lane == 0) p.epochs[blockIdx.x] = epoch;
+}
+
+template <int MODE, bool IP, int NCH>
+__global__ void __launch_bounds__(64, 3) roar_search_kernel(const RoarSearchParams p) {
+    search_one_wave<MODE, IP, NCH>(p);
+}
+
+// The same code under its own symbol for the searches the graph builder issues (LDS visited mode), so that a
+// kernel trace of a process that builds and then serves keeps the two apart (rocprofv3 --stats groups by name).
+template <bool IP, int NCH>
+__global__ void __launch_bounds__(64, 3) roar_build_search_kernel(const RoarSearchParams p) {
+    search_one_wave<VIS_LDS, IP, NCH>(p);
 }
 
 // Latency form of the same search: one 256-thread workgroup (4 waves) per query.  Wave 0 runs the
@@ -1005,6 +1017,13 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 
 template <int MODE, bool IP>
 const void *pick_nch(uint32_t dim, int mw) {
+    if (mw == 4) {  // one wave per query, builder's own symbol
+        switch (dim >> 4) {
+            case 8: return (const void *)roar_build_search_kernel<IP, 8>;
+            case 12: return (const void *)roar_build_search_kernel<IP, 12>;
+            default: return (const void *)roar_build_search_kernel<IP, 0>;
+        }
+    }
     if (mw == 3) {  // bipartite two-hop walk, eight waves per query (visited: u32 epoch tags, test-and-set)
         switch (dim >> 4) {
             case 8: return (const void *)roar_bipartite_kernel_wg<IP, 8>;

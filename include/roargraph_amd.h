@@ -239,8 +239,9 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq; power of two)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
- *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query
- *                    (latency form; auto picks it when the whole batch is resident that way)
+ *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
+ *                    3 two waves per query; auto picks four waves while the whole batch is resident that way,
+ *                    else two waves while it is resident that way, else one
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
  *                    threads while a launch is in flight share the next launch (the reference's harness calls

@@ -363,13 +363,20 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         mw = bp_wg ? 3 : 2;
         int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, mw, idx->dim_pad, p.lds_bytes, &occ);
         if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
-    } else if (idx->search_kernel != 1) {
-        int occ_mw = 0;
-        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 1, idx->dim_pad, p.lds_bytes, &occ_mw);
-        if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
-        if (occ_mw >= 1 && (idx->search_kernel == 2 || nq <= (uint64_t)occ_mw * (uint64_t)idx->n_cus)) {
-            mw = 1;
-            occ = occ_mw;
+    } else if (idx->search_kernel != 1 && !idx->building) {
+        // four waves per query while the whole batch is resident that way, else two waves per query while it is
+        // resident that way, else one (search_kernel: 0 auto, 1 one wave, 2 four waves, 3 two waves)
+        for (int form : {1, 5}) {
+            if (idx->search_kernel == 2 && form != 1) continue;
+            if (idx->search_kernel == 3 && form != 5) continue;
+            int occ_mw = 0;
+            int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, form, idx->dim_pad, p.lds_bytes, &occ_mw);
+            if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+            if (occ_mw >= 1 && (idx->search_kernel != 0 || nq <= (uint64_t)occ_mw * (uint64_t)idx->n_cus)) {
+                mw = form;
+                occ = occ_mw;
+                break;
+            }
         }
     }
     if (!mw) {
@@ -1510,7 +1517,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         if (value < 0 || (value & (value - 1))) return fail(ROAR_ERR_ARG, "vis_entries must be 0 or a power of two");
         idx->vis_entries = (int)value;
     } else if (k == "search_kernel") {
-        if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1 or 2");
+        if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
         idx->search_kernel = (int)value;
     } else if (k == "combine_single_queries") {
         idx->combine = value ? 1 : 0;
@@ -1540,7 +1547,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
-    else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : idx->last_mw == 3 ? 8 : 1;
+    else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : idx->last_mw == 3 ? 8 : idx->last_mw == 5 ? 2 : 1;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

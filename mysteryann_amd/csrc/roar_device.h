@@ -67,7 +67,7 @@ extern "C" {
 // Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
 // visited_mode: 0 exact tags, 1 LDS table.  multi_wave: 0 one wave per query, 1 four waves per query,
 // 2 bipartite two-hop walk (one wave per query), 3 bipartite two-hop walk (eight waves per query),
-// 4 one wave per query under the builder's kernel symbol (LDS visited mode only).  Returns a hipError_t value (0 = success).
+// 4 one wave per query under the builder's kernel symbol (LDS visited mode only), 5 two waves per query.  Returns a hipError_t value (0 = success).
 int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave, uint32_t grid,
                        void *stream);
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);

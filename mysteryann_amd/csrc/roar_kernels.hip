@@ -446,14 +446,15 @@ __global__ void __launch_bounds__(64, 3) roar_build_search_kernel(const RoarSear
     search_one_wave<VIS_LDS, IP, NCH>(p);
 }
 
-// Latency form of the same search: one 256-thread workgroup (4 waves) per query.  Wave 0 runs the
+// Latency form of the same search: one workgroup of W waves (4 or 2) per query.  Wave 0 runs the
 // sequential part exactly as roar_search_kernel does (select, adjacency, visited filter, merge); the
-// row gathers of a hop -- up to 128 candidates -- are spread over all four waves, 32 rows each with both
-// 16-row passes in flight, so a hop costs one adjacency round trip + one row round trip instead of
-// one per 16 rows.  Used when the whole batch fits the chip as 4-wave workgroups (small batches, the
-// per-query facade); results are the same by construction (same routines, same merge).
-template <int MODE, bool IP, int NCH>
-__global__ void __launch_bounds__(256) roar_search_kernel_mw(const RoarSearchParams p) {
+// row gathers of a hop -- up to 128 candidates -- are spread over the W waves (32 rows each with both
+// 16-row passes in flight for W = 4, 64 rows each for W = 2), so a hop costs one adjacency round trip + one
+// or two row round trips instead of one per 16 rows.  Used when the whole batch fits the chip that way
+// (W = 4: small batches and the per-query facade; W = 2: the batch sizes between that and the one-wave
+// throughput form); results are the same by construction (same routines, same merge).
+template <int MODE, bool IP, int NCH, int W>
+__global__ void __launch_bounds__(64 * W) roar_search_kernel_mw(const RoarSearchParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
@@ -474,15 +475,15 @@ __global__ void __launch_bounds__(256) roar_search_kernel_mw(const RoarSearchPar
         const uint32_t q = ctrl[0];
         if (q >= p.nq) break;
         const float *qp = p.queries + (u64)q * p.qstride;
-        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 1024)
+        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
             *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
         if (MODE == VIS_LDS) {
             const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;
-            for (uint32_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
         } else {
             epoch++;
             if (epoch == 256u) {
-                for (u64 i = (u64)threadIdx.x * 16; i < p.tag_stride; i += 4096)
+                for (u64 i = (u64)threadIdx.x * 16; i < p.tag_stride; i += 1024 * W)
                     *reinterpret_cast<uint4 *>(tags + i) = make_uint4(0, 0, 0, 0);
                 __threadfence();
                 epoch = 1;
@@ -549,9 +550,10 @@ __global__ void __launch_bounds__(256) roar_search_kernel_mw(const RoarSearchPar
             __syncthreads();
             const uint32_t m = ctrl[1];
             if (m == DONE) break;
-            const uint32_t lo = (uint32_t)wid * 32u;
+            constexpr uint32_t PER = 128u / W;  // rows per wave and hop
+            const uint32_t lo = (uint32_t)wid * PER;
             if (lo < m)
-                score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid + lo, ck + lo, (m - lo < 32u) ? m - lo : 32u, lane);
+                score_candidates<IP, NCH>(p.base, p.ld, p.dim, lq, cid + lo, ck + lo, (m - lo < PER) ? m - lo : PER, lane);
             __syncthreads();
             if (wid == 0 && m) {
                 merge_candidates(pool, ck, m < 64u ? m : 64u, L, psize, cur, lane);
@@ -1017,6 +1019,13 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 
 template <int MODE, bool IP>
 const void *pick_nch(uint32_t dim, int mw) {
+    if (mw == 5) {  // two waves per query
+        switch (dim >> 4) {
+            case 8: return (const void *)roar_search_kernel_mw<MODE, IP, 8, 2>;
+            case 12: return (const void *)roar_search_kernel_mw<MODE, IP, 12, 2>;
+            default: return (const void *)roar_search_kernel_mw<MODE, IP, 0, 2>;
+        }
+    }
     if (mw == 4) {  // one wave per query, builder's own symbol
         switch (dim >> 4) {
             case 8: return (const void *)roar_build_search_kernel<IP, 8>;
@@ -1040,13 +1049,15 @@ const void *pick_nch(uint32_t dim, int mw) {
     }
     switch (dim >> 4) {
         case 8:  // D = 128 (136)
-            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 8> : (const void *)roar_search_kernel<MODE, IP, 8>;
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 8, 4> : (const void *)roar_search_kernel<MODE, IP, 8>;
         case 12:  // D = 200 (192)
-            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 12> : (const void *)roar_search_kernel<MODE, IP, 12>;
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 12, 4> : (const void *)roar_search_kernel<MODE, IP, 12>;
         default:
-            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 0> : (const void *)roar_search_kernel<MODE, IP, 0>;
+            return mw ? (const void *)roar_search_kernel_mw<MODE, IP, 0, 4> : (const void *)roar_search_kernel<MODE, IP, 0>;
     }
 }
+
+int block_threads(int mw) { return mw == 1 ? 256 : mw == 3 ? 64 * BPW : mw == 5 ? 128 : 64; }
 
 const void *pick_kernel(int metric_ip, int visited_mode, uint32_t dim, int mw) {
     if (visited_mode == VIS_EXACT)
@@ -1065,7 +1076,7 @@ extern "C" int roar_launch_search(const RoarSearchParams *p, int metric_ip, int 
     }
     RoarSearchParams params = *p;
     void *args[] = {&params};
-    return (int)hipLaunchKernel(fn, dim3(grid), dim3(multi_wave == 1 ? 256 : multi_wave == 3 ? 64 * BPW : 64), args, p->lds_bytes, (hipStream_t)stream);
+    return (int)hipLaunchKernel(fn, dim3(grid), dim3(block_threads(multi_wave)), args, p->lds_bytes, (hipStream_t)stream);
 }
 
 extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
@@ -1075,8 +1086,7 @@ extern "C" int roar_search_occupancy(int metric_ip, int visited_mode, int multi_
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, multi_wave == 1 ? 256 : multi_wave == 3 ? 64 * BPW : 64,
-                                                             lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, block_threads(multi_wave), lds_bytes);
 }
 
 extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {

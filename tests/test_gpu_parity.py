@@ -491,12 +491,13 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
     for case in ("ip_200", "l2_128"):
         exp = np.load(os.path.join(golden_dir, case + ".expected.npz"))
         idx, q = _index(case, golden_dir, mode)
-        idx.set_option("search_kernel", 2)
-        for L in LS:
-            r = idx.SearchRoarGraphBatch(q, K, L)
-            assert idx.info("last_waves_per_query") == 4
-            for key in ("ids", "dists", "hops", "scanned", "cmps"):
-                assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, L, key)
+        for kernel, waves in ((2, 4), (3, 2)):
+            idx.set_option("search_kernel", kernel)
+            for L in LS:
+                r = idx.SearchRoarGraphBatch(q, K, L)
+                assert idx.info("last_waves_per_query") == waves
+                for key in ("ids", "dists", "hops", "scanned", "cmps"):
+                    assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, kernel, L, key)
         idx.close()
     n, d, nq = 5000, 200, 24
     base, q, off, nbrs = _random_case(n, d, nq, 1, seed=31, maxdeg=200)
@@ -504,7 +505,7 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
     idx.SetBaseData(base)
     idx.SetProjectionGraph(2, off, nbrs)
     idx.set_option("visited_mode", mode)
-    for kernel in (2, 1, 0):
+    for kernel in (2, 3, 1, 0):
         idx.set_option("search_kernel", kernel)
         for L in (10, 130, 700):
             o = oracle.search_batch(base, off, nbrs, 2, q, K, L, 1)

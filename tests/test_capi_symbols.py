@@ -71,3 +71,20 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "roar_oracle" not in text and "liboracle" not in text, f
+
+
+def test_bench_cli_parses_and_refuses_to_run_without_a_gpu():
+    """bench.py is the driver's entry point: its flags must parse here, and without a GPU it must stop with a
+    clear message instead of falling back to anything."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--sharded" in r.stdout
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)

@@ -85,9 +85,12 @@ def main():
     ap.add_argument("--visited", default="auto", choices=["auto", "lds", "exact"])
     ap.add_argument("--build-M", type=int, default=16)
     ap.add_argument("--build-basecap", type=int, default=64)
-    ap.add_argument("--build-maxdeg", type=int, default=200,
-                    help="row capacity of the built graph (hub rows fill it; 128 -> 160 -> 200 -> 256 moves recall 0.9 on T2I-10M "
-                         "from L_pq 55 to 40 to 30 to 25 at 5.83 / 5.57 / 5.52 / 5.99 ms per 10 k queries)")
+    ap.add_argument("--build-maxdeg", type=int, default=384,
+                    help="room in which a row of the built graph collects proposals (hub rows fill any room they get)")
+    ap.add_argument("--build-keep", type=int, default=128,
+                    help="> 0: after every build phase a row longer than KEEP keeps its KEEP nearest neighbours.  T2I-10M, "
+                         "recall 0.9: first come first kept, room 128 / 200 -> L_pq 55 / 30 at 5.83 / 5.52 ms per 10 k queries; "
+                         "room 384, KEEP 128 -> L_pq 30 at 3.92 ms (KEEP 184, room 512: L_pq 20 at 3.96 ms)")
     ap.add_argument("--build-L", type=int, default=48)
     ap.add_argument("--build-Msq", type=int, default=48)
     ap.add_argument("--build-Mpj", type=int, default=24)
@@ -178,7 +181,7 @@ def main():
                             supply_L=args.build_supplyL, L_learn_last=args.build_Llast,
                             trim_min_proj=args.build_trim[0], trim_keep_base=args.build_trim[1],
                             phase1_cand=args.build_C1, supply_cand=args.build_C3, proj_mode=args.build_projmode,
-                            supply_mode=args.build_supplymode)
+                            supply_mode=args.build_supplymode, row_keep=args.build_keep)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     log(f"[rank {rank}] bootstrap graph: {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
@@ -309,7 +312,7 @@ def main():
                    else f"{args.workload}-shape-n{args.n}", "n_base": args.n,
                    "dim": args.dim, "metric": "l2" if metric == mi.L2 else "ip", "n_queries_per_gpu": args.nq, "k": args.k, "L_pq": chosen,
                    "recall_at_10": rec, "parallelism": f"query batches sharded over {world} GPU(s), index replicated, no collective",
-                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")], "index": f"skeleton M={args.build_M}/{args.build_C1} cap={args.build_basecap}/{args.build_maxdeg} "
+                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")], "index": f"skeleton M={args.build_M}/{args.build_C1} cap={args.build_basecap}/{args.build_maxdeg}/{args.build_keep} "
                                                       f"L={args.build_L}; projection learn={n_learn} Msq={args.build_Msq} "
                                                       f"Mpj={args.build_Mpj} L={args.build_Llearn} x{args.build_rounds}; supply "
                                                       f"{args.build_supply}/{args.build_C3} L={args.build_supplyL}; trim "

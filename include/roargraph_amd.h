@@ -121,6 +121,9 @@ typedef struct roar_build_params {
     uint32_t trim_min_proj;  /* at the end: rows with >= trim_min_proj projection / supply edges keep only their */
     uint32_t trim_keep_base; /* first trim_keep_base phase-1 edges (0 / 0 = keep everything).  Applied only when
                                 phase 1 used another metric than the index (phase1_l2 on an IP / COSINE index) */
+    uint32_t row_keep;       /* 0: rows are filled first come first kept up to max_degree.  > 0: max_degree is only the
+                                room in which a row collects proposals; after every phase a row longer than row_keep
+                                keeps its row_keep neighbours nearest to the node itself (index metric), nearest first */
 } roar_build_params;
 int roar_build_graph(roar_index *idx, const roar_build_params *params);
 

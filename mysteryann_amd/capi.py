@@ -37,7 +37,7 @@ class BuildParams(C.Structure):
                 ("learn_knn_dev", C.c_void_p), ("supply_k", C.c_uint32), ("supply_L", C.c_uint32),
                 ("L_learn_last", C.c_uint32), ("phase1_cand", C.c_uint32), ("supply_cand", C.c_uint32),
                 ("proj_mode", C.c_uint32), ("supply_mode", C.c_uint32), ("no_skeleton", C.c_uint32),
-                ("trim_min_proj", C.c_uint32), ("trim_keep_base", C.c_uint32)]
+                ("trim_min_proj", C.c_uint32), ("trim_keep_base", C.c_uint32), ("row_keep", C.c_uint32)]
 
 
 class RoarError(RuntimeError):

@@ -355,6 +355,73 @@ __global__ void dedupe_rows_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, 
     row[0] = out;
 }
 
+// Rows longer than `keep` are cut back to the `keep` neighbours nearest to the node itself (index metric),
+// nearest first.  Hub rows collect far more proposals than they may hold; which of them stay decides how
+// much a hop through the hub is worth (first come first kept: recall 0.9 at L_pq = 30 on T2I-10M; nearest kept:
+// at L_pq = 20).  One wave per long row: distances to the node's own vector (row gathers, four neighbours in
+// flight), rank by counting in LDS, rewrite.
+template <bool IP>
+__global__ void __launch_bounds__(64) cut_rows_kernel(uint32_t *adj, uint32_t S, uint32_t cap, uint32_t keep,
+                                                      const float *__restrict__ base, u64 ld, uint32_t dim, u64 n,
+                                                      uint32_t *base_deg) {
+    extern __shared__ __align__(16) unsigned char cut_smem[];
+    u64 *keys = reinterpret_cast<u64 *>(cut_smem);                  // [1024]
+    uint32_t *ids_l = reinterpret_cast<uint32_t *>(cut_smem + 8192);  // [1024]
+    float *hv = reinterpret_cast<float *>(cut_smem + 12288);          // [dim]
+    const int lane = threadIdx.x;
+    for (u64 v = blockIdx.x; v < n; v += gridDim.x) {
+        uint32_t *row = adj + v * S;
+        uint32_t deg = row[0] < cap ? row[0] : cap;
+        if (deg > 1024u) deg = 1024u;
+        if (deg <= keep) continue;
+        const float *hrow = base + v * ld;
+        for (uint32_t i = lane * 4; i < dim; i += 256)
+            *reinterpret_cast<float4 *>(hv + i) = *reinterpret_cast<const float4 *>(hrow + i);
+        for (uint32_t j = lane; j < deg; j += 64) ids_l[j] = row[1 + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j0 = 0; j0 < deg; j0 += 4) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = j0 + u < deg ? j0 + u : deg - 1;
+                const float *r = base + (u64)ids_l[j] * ld;
+                for (uint32_t i = lane * 4; i < dim; i += 256) {
+                    const float4 x = *reinterpret_cast<const float4 *>(r + i);
+                    const float4 y = *reinterpret_cast<const float4 *>(hv + i);
+                    if (IP) {
+                        acc[u] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                    } else {
+                        const float a = x.x - y.x, b = x.y - y.y, c = x.z - y.z, e = x.w - y.w;
+                        acc[u] += a * a + b * b + c * c + e * e;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = wave_sum(acc[u]);
+                if (lane == 0 && j0 + u < deg) keys[j0 + u] = ((u64)f2ord_b(IP ? -t : t) << 32) | (j0 + u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i < deg; i += 64) {
+            const u64 key = keys[i];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < deg; ++q) rank += keys[q] < key ? 1u : 0u;
+            if (rank < keep) row[1 + rank] = ids_l[i];
+        }
+        if (lane == 0) {
+            row[0] = keep;
+            if (base_deg) base_deg[v] = 0;  // the row is no longer [phase-1 edges | projection edges]
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // optional trim: a row that received at least `min_proj` projection edges keeps only its first
 // `keep_base` phase-1 (base-to-base) edges; rows are [phase-1 edges | projection edges].
 __global__ void trim_base_edges_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, u64 n,
@@ -394,6 +461,19 @@ extern "C" {
 int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream) {
     hipLaunchKernelGGL(dedupe_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
                        max_deg, (u64)n);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_cut_rows(uint32_t *adj, uint32_t S, uint32_t cap, uint32_t keep, const float *base, uint64_t ld, uint32_t dim,
+                     int metric_ip, uint64_t n, uint32_t *base_deg, void *stream) {
+    const size_t lds = 12288 + (size_t)dim * sizeof(float);
+    const uint32_t grid = (uint32_t)(n < 8192 ? n : 8192);
+    if (metric_ip)
+        hipLaunchKernelGGL(cut_rows_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap, keep, base,
+                           (u64)ld, dim, (u64)n, base_deg);
+    else
+        hipLaunchKernelGGL(cut_rows_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap, keep, base,
+                           (u64)ld, dim, (u64)n, base_deg);
     return (int)hipGetLastError();
 }
 

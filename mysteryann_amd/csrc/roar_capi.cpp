@@ -36,6 +36,8 @@ int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint
 int roar_bk_trim(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, uint64_t n, uint32_t min_proj,
                  uint32_t keep_base, void *stream);
 int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
+int roar_bk_cut_rows(uint32_t *adj, uint32_t S, uint32_t cap, uint32_t keep, const float *base, uint64_t ld, uint32_t dim,
+                     int metric_ip, uint64_t n, uint32_t *base_deg, void *stream);
 int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
                          void *stream);
 }
@@ -856,6 +858,14 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     const int proj_ip = (bp->proj_mode == 1) ? 0 : (idx->ip ? 1 : 0);
     const int proj_flags = (bp->proj_mode == 2) ? 3 : 0;
     const uint32_t proj_cap = bp->no_skeleton ? std::min(max_degree, Mp) : max_degree;
+    // row_keep: max_degree is only the room in which a row collects proposals; after every phase rows longer than
+    // row_keep keep their row_keep nearest neighbours (index metric)
+    const uint32_t row_keep = (bp->row_keep && bp->row_keep < max_degree) ? bp->row_keep : 0;
+    auto cut_rows = [&]() -> int {
+        if (!row_keep) return 0;
+        return roar_bk_cut_rows(idx->adj, S, max_degree, row_keep, idx->base, idx->ld, idx->dim_pad, saved_ip ? 1 : 0, n,
+                                base_deg, nullptr);
+    };
     // phase 2: projection of the training queries, `rounds` times over the improving graph
     // exact learn -> base kNN lists (the reference builder's input, LoadLearnBaseKNN,
     // src/index_bipartite.cpp:2622-2639) are projected first when the caller has them
@@ -867,6 +877,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                                       -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
+        BK_TRY(cut_rows());
     }
     for (uint32_t r = 0; r < rounds && n_learn; ++r) {
         for (uint64_t a = 0; a < n_learn; a += max_batch) {
@@ -881,6 +892,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                                       1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
+        BK_TRY(cut_rows());
     }
     // phase 3: connectivity supplement in the index metric
     if (bp->supply_k) {
@@ -905,6 +917,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         }
     }
     BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
+    BK_TRY(cut_rows());
     // optional: drop phase-1 (skeleton) edges from rows that now hold enough projection / supply edges
     // (only when the skeleton was linked under another metric than the index's: an L2 index's skeleton IS
     // its graph -- trimming it on the SIFT shape drops recall from 0.95 to 0.42 at L_pq = 100)

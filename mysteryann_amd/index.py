@@ -104,7 +104,7 @@ class IndexBipartite:
     def BuildBootstrapGraph(self, M=16, base_cap=64, max_degree=128, L_build=48, max_batch=0, learn=None, M_sq=48,
                             M_pj=24, L_learn=128, rounds=2, phase1_l2=True, learn_knn=None, supply_k=12, supply_L=128,
                             L_learn_last=256, trim_min_proj=8, trim_keep_base=0, phase1_cand=48, supply_cand=48,
-                            proj_mode=0, supply_mode=0, no_skeleton=False):
+                            proj_mode=0, supply_mode=0, no_skeleton=False, row_keep=0):
         """In-HBM bootstrap builder (roar_build_graph): NOT the reference's BuildRoarGraph; it exists so
         that full-size synthetic indexes can be made on the GPU box.  `learn`: optional CUDA/HIP torch
         tensor of training queries [n_learn, stride >= dim_padded]."""
@@ -114,7 +114,7 @@ class IndexBipartite:
                               supply_L=supply_L,
                               L_learn_last=L_learn_last, trim_min_proj=trim_min_proj, trim_keep_base=trim_keep_base,
                               phase1_cand=phase1_cand, supply_cand=supply_cand, proj_mode=proj_mode,
-                              supply_mode=supply_mode, no_skeleton=1 if no_skeleton else 0)
+                              supply_mode=supply_mode, no_skeleton=1 if no_skeleton else 0, row_keep=row_keep)
         if learn is not None:
             assert learn.is_cuda and learn.is_contiguous()
             bp.learn_dev, bp.n_learn, bp.learn_stride_floats = learn.data_ptr(), learn.shape[0], learn.shape[1]

@@ -1066,3 +1066,41 @@ def test_combined_calls_keep_their_own_errors(built_lib):
             else:
                 assert tag == "ok" and np.array_equal(val, want["ids"][t]), (t, tag, val)
     idx.close()
+
+
+def test_builder_row_keep_cuts_long_rows_to_their_nearest_neighbours(built_lib):
+    """row_keep: rows collect proposals up to max_degree and are cut back to their row_keep nearest neighbours
+    (index metric), nearest first.  Checked against numpy on every long row; the graph must still answer queries
+    with the CPU checker's results."""
+    import torch
+
+    import oracle
+    from mysteryann_amd import fileio, synth
+    from mysteryann_amd import index as mi
+    from tests.golden.small_builder import exact_knn
+
+    n, d, keep = 30_000, 200, 48
+    base, q, learn = synth.t2i_numpy(n, 200, d, seed=3, n_learn=n)
+    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    lt = torch.from_numpy(fileio.pad_rows(learn)).cuda()
+    idx.BuildBootstrapGraph(learn=lt, max_degree=160, row_keep=keep)
+    ep, off, nbrs = idx.GetProjectionGraph()
+    deg = np.diff(off.astype(np.int64))
+    # rows may exceed keep only through the orphan rescue / supply of the last phase's tail: none here
+    assert deg.max() <= keep and deg.mean() > 15
+    full = np.nonzero(deg == keep)[0]
+    assert len(full) > 50  # the hubs of this set
+    for v in full[:200]:
+        row = nbrs[int(off[v]):int(off[v + 1])]
+        dots = base[row].astype(np.float64) @ base[v].astype(np.float64)
+        assert (np.diff(dots) <= 1e-6 * np.abs(dots).max()).all(), v  # nearest (largest inner product) first
+        assert v not in row and len(set(row.tolist())) == len(row)
+    gt, _ = exact_knn(q, base, 10, 1)
+    bp, qp = fileio.pad_rows(base), fileio.pad_rows(q)
+    for L in (20, 60):
+        r = idx.SearchRoarGraphBatch(q, K, L)
+        o = oracle.search_batch(bp, off, nbrs, ep, qp, K, L, 1, threads=4)
+        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"]), L
+    assert oracle.recall(r["ids"], gt, 10) > 0.9
+    idx.close()

@@ -19,7 +19,7 @@ args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
 base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n)
 idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=200)  # bench.py defaults; torch.cuda.synchronize(); del learn
+t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn  # bench.py defaults
 print(f"index built in {time.time() - t0:.1f}s, avg degree {idx.info('nedges') / n:.1f}", flush=True)
 gt = idx.ExactKnnDevice(queries, k, want_dists=False)[0].to(torch.int64)
 impl = "ref" if oracle.have_ref() else "port"

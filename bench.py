@@ -381,7 +381,7 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
     _, queries, learn = synth.t2i_torch(1024, nq, d, seed=args.seed, n_learn=n_learn, device=dev)  # same queries on every rank
     idx = mi.IndexBipartite(d, m, mi.INNER_PRODUCT, None, device=dev.index or 0)
     idx.SetBaseData(base)
-    idx.BuildBootstrapGraph(learn=learn, max_degree=args.build_maxdeg)
+    idx.BuildBootstrapGraph(learn=learn, max_degree=args.build_maxdeg, row_keep=args.build_keep)
     torch.cuda.synchronize()
     del learn
     log(f"[rank {rank}] shard of {m} points generated and indexed in {time.time() - t0:.1f}s, avg degree "

@@ -19,11 +19,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shards", type=int, default=8)
 ap.add_argument("--per-shard", type=int, default=12_500_000)
 ap.add_argument("--nq", type=int, default=10_000)
-ap.add_argument("--L", type=int, nargs="+", default=[15, 20, 30, 60], help="L_pq values, all on one build per shard")
+ap.add_argument("--L", type=int, nargs="+", default=[10, 15, 20, 30], help="L_pq values, all on one build per shard")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--check", type=int, default=200)
 ap.add_argument("--learn", type=int, default=1_250_000)
-ap.add_argument("--maxdeg", type=int, default=200)
+ap.add_argument("--maxdeg", type=int, default=384)
+ap.add_argument("--keep", type=int, default=128)
 args = ap.parse_args()
 
 import oracle
@@ -51,7 +52,7 @@ for s in range(S):
     _, _, learn = synth.t2i_torch(1024, 1, d, seed=1234, n_learn=args.learn)
     idx = mi.IndexBipartite(d, m, mi.INNER_PRODUCT, None)
     idx.SetBaseData(base)
-    idx.BuildBootstrapGraph(learn=learn, max_degree=args.maxdeg)
+    idx.BuildBootstrapGraph(learn=learn, max_degree=args.maxdeg, row_keep=args.keep)
     torch.cuda.synchronize()
     build_s.append(time.time() - t0)
     del learn

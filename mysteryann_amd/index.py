@@ -107,7 +107,9 @@ class IndexBipartite:
                             proj_mode=0, supply_mode=0, no_skeleton=False, row_keep=0):
         """In-HBM bootstrap builder (roar_build_graph): NOT the reference's BuildRoarGraph; it exists so
         that full-size synthetic indexes can be made on the GPU box.  `learn`: optional CUDA/HIP torch
-        tensor of training queries [n_learn, stride >= dim_padded]."""
+        tensor of training queries [n_learn, stride >= dim_padded].  row_keep > 0: max_degree is only the room in
+        which a row collects proposals; after every phase a row longer than row_keep keeps its row_keep nearest
+        neighbours (index metric), nearest first."""
         bp = capi.BuildParams(M=M, base_cap=base_cap, max_degree=max_degree, L_build=L_build, max_batch=max_batch,
                               learn_dev=None, n_learn=0, learn_stride_floats=0, M_sq=M_sq, M_pj=M_pj,
                               L_learn=L_learn, rounds=rounds, phase1_l2=1 if phase1_l2 else 0, supply_k=supply_k,

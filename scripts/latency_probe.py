@@ -5,7 +5,7 @@ import torch
 from mysteryann_amd import index as mi, synth
 n, d, L = 10_000_000, 200, 30  # bench.py's default graph and operating point
 base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base); idx.BuildBootstrapGraph(learn=learn, max_degree=200); del learn
+idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); del learn
 for nq in (1, 64, 256, 700, 1000, 1250, 1500, 2000, 2500, 4000, 10000):
     row = [f"nq={nq:6d}"]
     for kern in (1, 3, 2):

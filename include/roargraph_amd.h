@@ -258,6 +258,13 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
 int roar_set_option(roar_index *idx, const char *key, int64_t value);
 int roar_get_info(roar_index *idx, const char *key, int64_t *value);
 
+/* Diagnostics (no reference counterpart): with option "profile_phases" = 1 the search runs an instrumented
+ * instantiation of the same kernel; this copies out, for the first nq queries of the most recent such launch,
+ * u64[nq][16] = shader-clock cycles of {whole query, select, adjacency fetch, visited filter, row scoring, merge},
+ * speculative adjacency fetches that were used, adjacency round trips paid, then wave 0's scoring passes: cycles
+ * {issuing loads, waiting + FMAs, reduction + packing}, number of passes, candidates that reached the merge; 3 spare. */
+int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
+
 /* InitVisitedListPool(num_threads)  include/index_bipartite.h:133: sizes the EXACT-mode tag pool
  * (one u8[n] list per resident wave).  Optional: done lazily by the first EXACT search. */
 int roar_init_visited_pool(roar_index *idx, uint32_t slots);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
     "roar_load_bipartite_file", "roar_save_bipartite_file", "roar_set_bipartite_csr", "roar_get_bipartite_csr",
     "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
-    "roar_search_bipartite_batch_device",
+    "roar_search_bipartite_batch_device", "roar_last_profile",
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
     l.roar_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     l.roar_init_visited_pool.argtypes = [vp, C.c_uint32]
+    l.roar_last_profile.argtypes = [vp, u64p, C.c_uint64]
     l.roar_load_bipartite_file.argtypes = [vp, C.c_char_p]
     l.roar_save_bipartite_file.argtypes = [vp, C.c_char_p]
     l.roar_set_bipartite_csr.argtypes = [vp, C.c_uint64, u64p, u32p]

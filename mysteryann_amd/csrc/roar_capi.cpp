@@ -107,9 +107,14 @@ struct roar_index {
     int waves_per_cu = 0;
     int vis_entries = 0;
     int max_grid = 0;
-    int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query
+    int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query, 3 two waves per query
+    int kernel_version = 2; // 1: first-generation kernels (kept for A/B runs)
+    int score_rows = 0;     // base rows per 4-lane group and scoring pass (0 auto, 2, 4)
+    int profile = 0;        // 1: instrumented kernel, phase timers readable with roar_last_profile
+    unsigned long long *prof_dev = nullptr;
+    uint64_t prof_cap = 0, prof_nq = 0;
     bool building = false;  // searches issued by roar_build_graph run under their own kernel symbol
-    int last_mw = 0;
+    RoarKernelSel last_sel = {};
     // workspaces
     uint32_t *counters = nullptr;  // [0] dequeue counter, [1] short count
     uint8_t *tags = nullptr;
@@ -219,11 +224,26 @@ int upload_rows(roar_index *idx, const float *padded, uint64_t r0, uint64_t cnt)
     return ROAR_OK;
 }
 
-int ensure_tags(roar_index *idx, uint32_t slots) {
+// Visited-tag pools cost slots x n bytes (u8 tags) or slots x 4 n bytes (u32 tags) of HBM.  A pool never takes more
+// than half of what is free: the launch then runs with fewer resident workgroups instead of failing (a shard of
+// 100 M points still searches in EXACT mode, with a smaller grid).  *slots is lowered to what was granted.
+uint32_t affordable_slots(uint64_t bytes_per_slot, uint64_t already_held, uint32_t want) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
+    const uint64_t budget = ((uint64_t)free_b + already_held) / 2;
+    const uint64_t fit = budget / std::max<uint64_t>(bytes_per_slot, 1);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, fit));
+}
+
+int ensure_tags(roar_index *idx, uint32_t *slots_io) {
+    uint32_t slots = *slots_io;
+    if (idx->tags && idx->slots >= slots) return ROAR_OK;
+    const uint64_t stride = std::max<uint64_t>(16, ((idx->n + 15) / 16) * 16);
+    slots = affordable_slots(stride, idx->tags ? (uint64_t)idx->slots * idx->tag_stride : 0, slots);
+    *slots_io = slots;
     if (idx->tags && idx->slots >= slots) return ROAR_OK;
     free_tags(idx);
-    idx->tag_stride = ((idx->n + 15) / 16) * 16;
-    if (idx->tag_stride == 0) idx->tag_stride = 16;
+    idx->tag_stride = stride;
     HIP_TRY(hipMalloc((void **)&idx->tags, (size_t)slots * idx->tag_stride));
     HIP_TRY(hipMemset(idx->tags, 0, (size_t)slots * idx->tag_stride));
     HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
@@ -232,14 +252,19 @@ int ensure_tags(roar_index *idx, uint32_t slots) {
     return ROAR_OK;
 }
 
-int ensure_tags32(roar_index *idx, uint32_t slots) {
+int ensure_tags32(roar_index *idx, uint32_t *slots_io) {
+    uint32_t slots = *slots_io;
+    if (idx->tags32 && idx->slots32 >= slots) return ROAR_OK;
+    const uint64_t stride = ((idx->n + 3) / 4) * 4;
+    slots = affordable_slots(stride * 4, idx->tags32 ? (uint64_t)idx->slots32 * idx->tag_stride32 * 4 : 0, slots);
+    *slots_io = slots;
     if (idx->tags32 && idx->slots32 >= slots) return ROAR_OK;
     if (idx->tags32) (void)hipFree(idx->tags32);
     if (idx->epochs32) (void)hipFree(idx->epochs32);
     idx->tags32 = nullptr;
     idx->epochs32 = nullptr;
     idx->slots32 = 0;
-    idx->tag_stride32 = ((idx->n + 3) / 4) * 4;
+    idx->tag_stride32 = stride;
     HIP_TRY(hipMalloc((void **)&idx->tags32, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->tags32, 0, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&idx->epochs32, (size_t)slots * sizeof(uint32_t)));
@@ -273,8 +298,11 @@ int ensure_host_csr(roar_index *idx) {
 
 struct LaunchPlan {
     RoarSearchParams p;
+    RoarKernelSel sel;
     uint32_t grid;
 };
+
+constexpr size_t ADJ_SLACK_WORDS = 256;  // a row read is up to 3 x 64 words from the row's first word
 
 // LDS carve-up and grid for one search launch.
 int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan, bool bipartite = false) {
@@ -341,9 +369,9 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
     p.off_ck = off;
-    off += bp_wg ? 8 * 64 * 8 : 8 * 128;   // eight waves x 64 keys in the workgroup form
+    off += bp_wg ? 8 * 64 * 8 : 8 * 192;   // eight waves x 64 keys in the workgroup form; else one adjacency round trip (3 x 64)
     p.off_cid = off;
-    off += bp_wg ? 4 * 64 * 8 : 4 * 128;
+    off += bp_wg ? 4 * 64 * 8 : 4 * 192;
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
     p.off_vis = off;
@@ -358,35 +386,59 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     }
     p.lds_bytes = off;
     if (p.lds_bytes > 160 * 1024) return fail(ROAR_ERR_ARG, "L_pq = %u needs %u bytes of LDS per query (max 163840)", L, off);
-    // kernel form: four waves per query when the whole batch is resident that way (latency form),
-    // one wave per query otherwise (throughput form)
-    int occ = 0, mw = 0;
-    if (bipartite) {
-        mw = bp_wg ? 3 : 2;
-        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, mw, idx->dim_pad, p.lds_bytes, &occ);
+    // kernel form: W waves per query while the whole batch is resident that way (latency forms), one wave per
+    // query otherwise (throughput form)
+    RoarKernelSel &sel = plan->sel;
+    memset(&sel, 0, sizeof sel);
+    sel.metric_ip = idx->ip ? 1 : 0;
+    sel.visited_mode = mode;
+    sel.form = idx->kernel_version == 1 ? ROAR_FORM_V1 : ROAR_FORM_V2;
+    sel.waves = 1;
+    sel.rows = idx->score_rows == 4 ? 4 : 2;
+    sel.prof = (idx->profile && sel.form == ROAR_FORM_V2) ? 1 : 0;
+    if (sel.prof) sel.rows = 2;
+    int occ = 0;
+    auto occupancy = [&](int *out) -> int {
+        int rc = roar_search_occupancy(&sel, idx->dim_pad, p.lds_bytes, out);
         if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+        return ROAR_OK;
+    };
+    bool picked = false;
+    if (bipartite) {
+        sel.form = bp_wg ? ROAR_FORM_BIPARTITE_WG : ROAR_FORM_BIPARTITE;
+        int e = occupancy(&occ);
+        if (e) return e;
+        picked = true;
+    } else if (idx->building && mode == ROAR_VISITED_LDS) {
+        sel.form = ROAR_FORM_BUILDER;
+        int e = occupancy(&occ);
+        if (e) return e;
+        picked = true;
     } else if (idx->search_kernel != 1 && !idx->building) {
         // four waves per query while the whole batch is resident that way, else two waves per query while it is
         // resident that way, else one (search_kernel: 0 auto, 1 one wave, 2 four waves, 3 two waves)
-        for (int form : {1, 5}) {
-            if (idx->search_kernel == 2 && form != 1) continue;
-            if (idx->search_kernel == 3 && form != 5) continue;
+        for (int w : {4, 2}) {
+            if (idx->search_kernel == 2 && w != 4) continue;
+            if (idx->search_kernel == 3 && w != 2) continue;
+            sel.waves = w;
+            if (w == 4) sel.rows = 2;
             int occ_mw = 0;
-            int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, form, idx->dim_pad, p.lds_bytes, &occ_mw);
-            if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+            int e = occupancy(&occ_mw);
+            if (e) return e;
             if (occ_mw >= 1 && (idx->search_kernel != 0 || nq <= (uint64_t)occ_mw * (uint64_t)idx->n_cus)) {
-                mw = form;
                 occ = occ_mw;
+                picked = true;
                 break;
             }
         }
     }
-    if (!mw) {
-        int rc = roar_search_occupancy(idx->ip ? 1 : 0, mode, 0, idx->dim_pad, p.lds_bytes, &occ);
-        if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+    if (!picked) {
+        sel.waves = 1;
+        sel.rows = (idx->score_rows == 4 && !sel.prof) ? 4 : 2;
+        int e = occupancy(&occ);
+        if (e) return e;
     }
-    if (!mw && idx->building && mode == ROAR_VISITED_LDS) mw = 4;
-    idx->last_mw = mw;
+    idx->last_sel = sel;
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
@@ -397,19 +449,34 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     if (bp_wg) {
         // u32 tags: 4 n bytes per resident workgroup; 256 workgroups keep every CU busy with eight waves each
         if (plan->grid > 256) plan->grid = 256;
-        int e = ensure_tags32(idx, std::max<uint32_t>(plan->grid, idx->slots32));
+        uint32_t slots = plan->grid;
+        int e = ensure_tags32(idx, &slots);
         if (e) return e;
+        plan->grid = std::min(plan->grid, std::max(slots, idx->slots32));
         p.tags32 = idx->tags32;
         p.tag_stride32 = idx->tag_stride32;
         p.epochs = idx->epochs32;
     } else if (mode == ROAR_VISITED_EXACT) {
-        int e = ensure_tags(idx, std::max<uint32_t>(plan->grid, idx->slots));
+        uint32_t slots = plan->grid;
+        int e = ensure_tags(idx, &slots);
         if (e) return e;
+        plan->grid = std::min(plan->grid, std::max(slots, idx->slots));
         p.tags = idx->tags;
         p.tag_stride = idx->tag_stride;
         p.epochs = idx->epochs;
     }
     p.counter = idx->counters;
+    if (sel.prof) {
+        if (idx->prof_cap < nq) {
+            if (idx->prof_dev) (void)hipFree(idx->prof_dev);
+            idx->prof_dev = nullptr;
+            idx->prof_cap = 0;
+            HIP_TRY(hipMalloc((void **)&idx->prof_dev, (size_t)nq * 16 * sizeof(unsigned long long)));
+            idx->prof_cap = nq;
+        }
+        p.prof = idx->prof_dev;
+        idx->prof_nq = nq;
+    }
     idx->last_grid = plan->grid;
     idx->last_lds = p.lds_bytes;
     idx->last_vis_entries = entries;
@@ -535,6 +602,7 @@ void roar_destroy(roar_index *idx) {
     if (idx->counters) (void)hipFree(idx->counters);
     if (idx->q_dev) (void)hipFree(idx->q_dev);
     if (idx->out_dev) (void)hipFree(idx->out_dev);
+    if (idx->prof_dev) (void)hipFree(idx->prof_dev);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     delete idx;
@@ -652,7 +720,7 @@ int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t 
     idx->max_deg = max_deg;
     // rows start on 128-byte lines; 64 words of slack so that a 64-lane chunk read never leaves the buffer
     idx->adj_stride = round_up(max_deg + 1, 32);
-    const size_t words = (size_t)n * idx->adj_stride + 64;
+    const size_t words = (size_t)n * idx->adj_stride + ADJ_SLACK_WORDS;
     HIP_TRY(hipMalloc((void **)&idx->adj, words * sizeof(uint32_t)));
     // Build rows in chunks.  A neighbour repeated inside one list is kept once (first occurrence):
     // the reference skips the repeat through its visited test (index_bipartite.cpp:2378), so the
@@ -677,7 +745,7 @@ int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t 
         HIP_TRY(hipMemcpy(idx->adj + r0 * idx->adj_stride, buf.data(), (size_t)cnt * idx->adj_stride * 4,
                           hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMemset(idx->adj + (size_t)n * idx->adj_stride, 0, 64 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->adj + (size_t)n * idx->adj_stride, 0, ADJ_SLACK_WORDS * sizeof(uint32_t)));
     return ROAR_OK;
 }
 
@@ -770,8 +838,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     free_graph(idx);
     const uint64_t n = idx->n;
     const uint32_t S = round_up(max_degree + 1, 32);
-    HIP_TRY(hipMalloc((void **)&idx->adj, ((size_t)n * S + 64) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(idx->adj, 0, ((size_t)n * S + 64) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&idx->adj, ((size_t)n * S + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(idx->adj, 0, ((size_t)n * S + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
     idx->adj_stride = S;
     idx->gn = n;
     idx->max_deg = max_degree;
@@ -986,7 +1054,8 @@ int roar_init_visited_pool(roar_index *idx, uint32_t slots) {
     if (!idx || idx->n == 0) return fail(ROAR_ERR_ARG, "InitVisitedListPool before the base vectors were loaded");
     int e = use_device(idx);
     if (e) return e;
-    return ensure_tags(idx, std::max<uint32_t>(slots, 1));
+    slots = std::max<uint32_t>(slots, 1);
+    return ensure_tags(idx, &slots);
 }
 
 int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats,
@@ -1014,7 +1083,7 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, idx->last_mw, plan.grid, st);
+    int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -1323,7 +1392,7 @@ int roar_search_bipartite_batch_device(roar_index *idx, const float *queries_dev
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, idx->ip ? 1 : 0, idx->last_mode, idx->last_mw, plan.grid, st);
+    int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -1516,6 +1585,17 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
     return ROAR_OK;
 }
 
+int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq) {
+    if (!idx || !out) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (!idx->prof_dev || idx->prof_nq == 0) return fail(ROAR_ERR_ARG, "no instrumented search has run (option profile_phases)");
+    if (nq > idx->prof_nq) return fail(ROAR_ERR_ARG, "the last instrumented launch had %llu queries", (unsigned long long)idx->prof_nq);
+    int e = use_device(idx);
+    if (e) return e;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, idx->prof_dev, (size_t)nq * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return ROAR_OK;
+}
+
 int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     if (!idx || !key) return fail(ROAR_ERR_ARG, "bad arguments");
     std::string k(key);
@@ -1532,6 +1612,14 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
         idx->search_kernel = (int)value;
+    } else if (k == "kernel_version") {
+        if (value != 1 && value != 2) return fail(ROAR_ERR_ARG, "kernel_version must be 1 or 2");
+        idx->kernel_version = (int)value;
+    } else if (k == "score_rows") {
+        if (value != 0 && value != 2 && value != 4) return fail(ROAR_ERR_ARG, "score_rows must be 0 (auto), 2 or 4");
+        idx->score_rows = (int)value;
+    } else if (k == "profile_phases") {
+        idx->profile = value ? 1 : 0;
     } else if (k == "combine_single_queries") {
         idx->combine = value ? 1 : 0;
     } else if (k == "bipartite_seed") {
@@ -1560,7 +1648,11 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
-    else if (k == "last_waves_per_query") *value = idx->last_mw == 1 ? 4 : idx->last_mw == 3 ? 8 : idx->last_mw == 5 ? 2 : 1;
+    else if (k == "last_waves_per_query")
+        *value = idx->last_sel.form == ROAR_FORM_BIPARTITE_WG ? 8
+                 : (idx->last_sel.form == ROAR_FORM_V1 || idx->last_sel.form == ROAR_FORM_V2) ? idx->last_sel.waves : 1;
+    else if (k == "last_score_rows") *value = idx->last_sel.rows;
+    else if (k == "kernel_version") *value = idx->kernel_version;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

@@ -46,6 +46,20 @@ struct RoarSearchParams {
     // eight-waves-per-query form: one u32[tag_stride32] epoch list per resident workgroup (test-and-set)
     uint32_t *tags32;
     uint64_t tag_stride32;
+    // per-query phase timers of the instrumented kernels (u64[nq][8]: total, select, adjacency, filter, score, merge
+    // shader-clock cycles of wave 0, speculative adjacency fetches that were used, adjacency round trips paid); may be null
+    unsigned long long *prof;
+};
+
+// Which kernel a launch runs.
+enum { ROAR_FORM_V2 = 0, ROAR_FORM_V1 = 1, ROAR_FORM_BIPARTITE = 2, ROAR_FORM_BIPARTITE_WG = 3, ROAR_FORM_BUILDER = 4 };
+struct RoarKernelSel {
+    int metric_ip;     // 1: negated inner product, 0: squared L2
+    int visited_mode;  // 0 exact tags in HBM, 1 LDS tag table
+    int form;          // ROAR_FORM_*
+    int waves;         // waves per query (1, 2, 4) of the V1 / V2 forms
+    int rows;          // V2: base rows per 4-lane group and scoring pass (2 or 4)
+    int prof;          // V2: instrumented instantiation (phase timers)
 };
 
 struct RoarDistParams {
@@ -64,18 +78,13 @@ struct RoarDistParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
-// Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.
-// visited_mode: 0 exact tags, 1 LDS table.  multi_wave: 0 one wave per query, 1 four waves per query,
-// 2 bipartite two-hop walk (one wave per query), 3 bipartite two-hop walk (eight waves per query),
-// 4 one wave per query under the builder's kernel symbol (LDS visited mode only), 5 two waves per query.  Returns a hipError_t value (0 = success).
-int roar_launch_search(const RoarSearchParams *p, int metric_ip, int visited_mode, int multi_wave, uint32_t grid,
-                       void *stream);
+// Host-side launchers implemented in roar_kernels.hip.  `stream` is a hipStream_t.  Return a hipError_t value (0 = success).
+int roar_launch_search(const RoarSearchParams *p, const RoarKernelSel *sel, uint32_t grid, void *stream);
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
-// Max resident single-wave workgroups per CU for the search kernel variant at this LDS size.
-int roar_search_occupancy(int metric_ip, int visited_mode, int multi_wave, uint32_t dim, uint32_t lds_bytes,
-                          int *blocks_per_cu);
+// Max resident workgroups per CU for the selected kernel at this LDS size.
+int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
 #ifdef __cplusplus
 }
 #endif

@@ -161,6 +161,13 @@ class IndexBipartite:
         capi.check(self._lib.roar_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
 
+    def LastProfile(self, nq):
+        """Phase timers of the most recent instrumented launch (option profile_phases): uint64 [nq, 16]
+        (layout: roar_last_profile in include/roargraph_amd.h)."""
+        out = np.zeros((nq, 16), np.uint64)
+        capi.check(self._lib.roar_last_profile(self._h, capi.u64p(out), int(nq)))
+        return out
+
     # ---- search ---------------------------------------------------------------------------------
     def SearchRoarGraph(self, query, k, qid, parameters, indices=None, res_dists=None):
         """index_bipartite.cpp:2311-2420 for ONE query; returns (cmps, hops) like the reference and

@@ -48,13 +48,12 @@ class RoarError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("roar_kernels.hip", "roar_build.hip", "roar_knn.hip", "roar_capi.cpp",
-                                             "roar_device.h")]
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h")) or f == "roar_capi.cpp"]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", _CSRC, "lib"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j8", "-C", _CSRC, "lib"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

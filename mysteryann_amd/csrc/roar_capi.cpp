@@ -108,8 +108,7 @@ struct roar_index {
     int vis_entries = 0;
     int max_grid = 0;
     int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query, 3 two waves per query
-    int kernel_version = 2; // 1: first-generation kernels (kept for A/B runs)
-    int score_rows = 0;     // base rows per 4-lane group and scoring pass (0 auto, 2, 4)
+    int pool_form = 0;      // 0 auto (register pool for L_pq <= 64), 1 always the LDS pool
     int profile = 0;        // 1: instrumented kernel, phase timers readable with roar_last_profile
     unsigned long long *prof_dev = nullptr;
     uint64_t prof_cap = 0, prof_nq = 0;
@@ -352,11 +351,15 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
     if (mode == ROAR_VISITED_LDS) {
-        // auto: 8192 tags (16 KB) for every L_pq: it leaves 8 waves per CU and was the fastest table from
-        // L_pq = 20 to 75 on T2I-10M (e.g. L_pq = 60: 6.84 / 6.46 / 6.09 / 7.26 ms at 2048 / 4096 / 8192 /
-        // 16384 entries; a smaller table re-scores more nodes, a larger one halves the occupancy;
-        // 12 waves per CU, which the smaller tables would allow, is no faster than 8)
-        uint32_t want = idx->vis_entries > 0 ? (uint32_t)idx->vis_entries : 8192u;
+        // auto: 8192 tags (16 KB, 8 waves per CU) at short pools and for batches that do not fill the chip; 16384 tags
+        // (32 KB, 4 waves per CU) once the pool is long enough for the small table to forget and there are queries
+        // enough to keep four waves per CU busy.  T2I-10M, 10 000 queries, 8192 / 16384 / 32768 tags: L_pq = 100
+        // 10.49 / 9.97 / 14.26 ms, 300: 26.79 / 24.05 / 35.45 ms, 500: 43.32 / 37.74 / 55.95 ms (cmps 36.5 k / 29.9 k
+        // against the reference's 27.0 k); 2 500 queries: 100: 2.81 / 2.87, 300: 7.21 / 7.04, 500: 11.61 / 11.02 ms;
+        // 1 250 queries: the small table wins everywhere (profiles/r02_kernel_forms.txt).  L_pq = 60: 6.09 vs 7.26 ms.
+        uint32_t want = 8192u;
+        if ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000)) want = 16384u;
+        if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
         while ((1u << sets_log2) < sets) sets_log2++;
@@ -377,7 +380,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_vis = off;
     off += 2 * entries;
     p.off_ctrl = off;
-    off += bp_wg ? 64 : 16;
+    off += bp_wg ? 64 : 32;
     if (bipartite) {
         p.off_bp = off;
         off += 768;
@@ -392,11 +395,12 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     memset(&sel, 0, sizeof sel);
     sel.metric_ip = idx->ip ? 1 : 0;
     sel.visited_mode = mode;
-    sel.form = idx->kernel_version == 1 ? ROAR_FORM_V1 : ROAR_FORM_V2;
+    sel.form = ROAR_FORM_SEARCH;
     sel.waves = 1;
-    sel.rows = idx->score_rows == 4 ? 4 : 2;
-    sel.prof = (idx->profile && sel.form == ROAR_FORM_V2) ? 1 : 0;
-    if (sel.prof) sel.rows = 2;
+    sel.regpool = (L <= 64 && idx->pool_form == 0) ? 1 : 0;
+    sel.prof = idx->profile ? 1 : 0;
+    if (sel.prof && !(idx->ip && idx->dim_pad == 200))
+        return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product shape only");
     int occ = 0;
     auto occupancy = [&](int *out) -> int {
         int rc = roar_search_occupancy(&sel, idx->dim_pad, p.lds_bytes, out);
@@ -406,11 +410,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     bool picked = false;
     if (bipartite) {
         sel.form = bp_wg ? ROAR_FORM_BIPARTITE_WG : ROAR_FORM_BIPARTITE;
+        sel.prof = sel.regpool = 0;
         int e = occupancy(&occ);
         if (e) return e;
         picked = true;
     } else if (idx->building && mode == ROAR_VISITED_LDS) {
         sel.form = ROAR_FORM_BUILDER;
+        sel.prof = 0;
         int e = occupancy(&occ);
         if (e) return e;
         picked = true;
@@ -421,7 +427,6 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
             if (idx->search_kernel == 2 && w != 4) continue;
             if (idx->search_kernel == 3 && w != 2) continue;
             sel.waves = w;
-            if (w == 4) sel.rows = 2;
             int occ_mw = 0;
             int e = occupancy(&occ_mw);
             if (e) return e;
@@ -434,7 +439,6 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     }
     if (!picked) {
         sel.waves = 1;
-        sel.rows = (idx->score_rows == 4 && !sel.prof) ? 4 : 2;
         int e = occupancy(&occ);
         if (e) return e;
     }
@@ -1612,12 +1616,9 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
         idx->search_kernel = (int)value;
-    } else if (k == "kernel_version") {
-        if (value != 1 && value != 2) return fail(ROAR_ERR_ARG, "kernel_version must be 1 or 2");
-        idx->kernel_version = (int)value;
-    } else if (k == "score_rows") {
-        if (value != 0 && value != 2 && value != 4) return fail(ROAR_ERR_ARG, "score_rows must be 0 (auto), 2 or 4");
-        idx->score_rows = (int)value;
+    } else if (k == "pool_form") {
+        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");
+        idx->pool_form = (int)value;
     } else if (k == "profile_phases") {
         idx->profile = value ? 1 : 0;
     } else if (k == "combine_single_queries") {
@@ -1650,9 +1651,8 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_visited_mode") *value = idx->last_mode;
     else if (k == "last_waves_per_query")
         *value = idx->last_sel.form == ROAR_FORM_BIPARTITE_WG ? 8
-                 : (idx->last_sel.form == ROAR_FORM_V1 || idx->last_sel.form == ROAR_FORM_V2) ? idx->last_sel.waves : 1;
-    else if (k == "last_score_rows") *value = idx->last_sel.rows;
-    else if (k == "kernel_version") *value = idx->kernel_version;
+                 : idx->last_sel.form == ROAR_FORM_SEARCH ? idx->last_sel.waves : 1;
+    else if (k == "last_register_pool") *value = idx->last_sel.regpool;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

@@ -52,14 +52,14 @@ struct RoarSearchParams {
 };
 
 // Which kernel a launch runs.
-enum { ROAR_FORM_V2 = 0, ROAR_FORM_V1 = 1, ROAR_FORM_BIPARTITE = 2, ROAR_FORM_BIPARTITE_WG = 3, ROAR_FORM_BUILDER = 4 };
+enum { ROAR_FORM_SEARCH = 0, ROAR_FORM_BIPARTITE = 2, ROAR_FORM_BIPARTITE_WG = 3, ROAR_FORM_BUILDER = 4 };
 struct RoarKernelSel {
     int metric_ip;     // 1: negated inner product, 0: squared L2
     int visited_mode;  // 0 exact tags in HBM, 1 LDS tag table
     int form;          // ROAR_FORM_*
-    int waves;         // waves per query (1, 2, 4) of the V1 / V2 forms
-    int rows;          // V2: base rows per 4-lane group and scoring pass (2 or 4)
-    int prof;          // V2: instrumented instantiation (phase timers)
+    int waves;         // SEARCH: waves per query (1, 2, 4)
+    int regpool;       // SEARCH / BUILDER: candidate pool in a register pair of wave 0 (L_pq <= 64) instead of LDS
+    int prof;          // SEARCH: instrumented instantiation (phase timers; Text-to-Image shape only)
 };
 
 struct RoarDistParams {

@@ -1,0 +1,5 @@
+// roar_search_exact_ip.hip -- SearchRoarGraph kernels, visited mode EXACT (u8 epoch tags in HBM), metric inner product
+// (one translation unit per pair so that the build runs in parallel; the code is roar_search_v2.h).
+#define ROAR_TU_MODE 0
+#define ROAR_TU_IP 1
+#include "roar_search_v2.h"

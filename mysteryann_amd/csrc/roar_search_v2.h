@@ -1,0 +1,654 @@
+// roar_search_v2.h -- the SearchRoarGraph kernel (src/index_bipartite.cpp:2311-2420) for gfx950, included by one
+// translation unit per (visited mode, metric) pair: roar_search_{lds,exact}_{ip,l2}.hip define ROAR_TU_MODE / ROAR_TU_IP.
+//
+// One workgroup of W waves (1, 2 or 4) owns one query at a time (persistent, dynamic dequeue).  Wave 0 runs the
+// sequential part of the reference's loop (:2356-2405) -- closest_unexpanded, the adjacency row, the visited test,
+// the inserts -- and every wave scores its share of the hop's base rows.  What a hop costs is counted in dependent
+// memory round trips and in instruction latency, so:
+//   * the whole adjacency row (up to 3 x 64 words) is fetched in ONE round trip;
+//   * while the rows of a hop are being scored, the adjacency row of the LIKELY next expansion (the closest
+//     unexpanded pool entry as it stands before the hop's merges) is already in flight; it is used if the merges
+//     leave that entry in front, dropped otherwise (results cannot depend on it);
+//   * the visited filter runs over the whole row at once (LDS mode: three compare-and-swaps per lane in flight;
+//     EXACT mode: the tag loads of all three chunks in flight), the survivors of the whole hop are packed, scored
+//     R x 16 rows per pass -- every load of a pass, the 8-float tail of a D = 200 row included, issued before the
+//     first FMA -- and keys a full pool would reject are dropped before the merge;
+//   * for L_pq <= 64 the candidate pool lives in ONE VGPR PAIR of wave 0 (lane i = i-th entry): closest_unexpanded is
+//     a ballot, the reject threshold a readlane, and a merge is one pass over the surviving candidates in which a
+//     ballot + popcount gives the lower bound (no binary search), the duplicate test and every other entry's shift.
+// Within a hop the order of the inserts cannot change the pool (top-L of a set, duplicate keys dropped), so packing a
+// hop's candidates is exact; cmps / hops / scanned are counted as the reference counts them.
+//
+// The kernel is HBM-gather bound (0.5 flop/byte): nothing here goes through MFMA on purpose.
+#pragma once
+#include "roar_wave.h"
+
+namespace {
+
+// LDS visited table, test-and-set of up to three ids per lane at once (one adjacency round trip).  Same table as
+// visited_filter<VIS_LDS> -- sets x 4 ways of u16 tags, (set, tag) <-> id a bijection, so a hit is never false -- but an
+// empty way is claimed with a 32-bit compare-and-swap on the half of the set that holds it: no write / barrier /
+// re-read round per insertion; a lane that loses a race sees the winner's word in the CAS result and tries the next
+// way.  The three probes of a lane are independent, so a round is written branch-free with the three atomics in
+// flight together.  A full set overwrites a victim way; that is the only place the table forgets (the node is then
+// scored again and its key is dropped by the merge as a duplicate or as worse than the pool's last entry).
+__device__ __forceinline__ void visited_lds3(const bool (&isn)[3], const uint32_t (&nb)[3], uint16_t *vis, uint32_t sets_mask,
+                                             uint32_t sets_log2, bool (&fresh)[3]) {
+    uint32_t *w[3];
+    uint32_t tag[3], x[3], y[3];
+    bool pend[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t set = nb[c] & sets_mask;
+        tag[c] = (nb[c] >> sets_log2) + 1u;
+        w[c] = reinterpret_cast<uint32_t *>(vis + 4 * set);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint2 ww = *reinterpret_cast<const uint2 *>(w[c]);
+        x[c] = ww.x;
+        y[c] = ww.y;
+        pend[c] = isn[c];
+        fresh[c] = false;
+    }
+    while (__ballot(pend[0] | pend[1] | pend[2])) {
+        bool cas[3], low[3];
+        uint32_t oldw[3], got[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t t0 = x[c] & 0xFFFFu, t1 = x[c] >> 16, t2 = y[c] & 0xFFFFu, t3 = y[c] >> 16;
+            const bool hit = (t0 == tag[c]) | (t1 == tag[c]) | (t2 == tag[c]) | (t3 == tag[c]);
+            const bool full = (t0 != 0) & (t1 != 0) & (t2 != 0) & (t3 != 0);
+            low[c] = (t0 == 0) | (t1 == 0);
+            oldw[c] = low[c] ? x[c] : y[c];
+            cas[c] = pend[c] & !hit & !full;
+            const bool victim = pend[c] & !hit & full;
+            if (victim) reinterpret_cast<uint16_t *>(w[c])[tag[c] & 3u] = (uint16_t)tag[c];
+            fresh[c] |= victim;
+            pend[c] = cas[c];  // visited before, or victim written: done
+            got[c] = oldw[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (cas[c])
+                got[c] = atomicCAS(w[c] + (low[c] ? 0 : 1), oldw[c], oldw[c] | (((oldw[c] & 0xFFFFu) == 0) ? tag[c] : (tag[c] << 16)));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool won = cas[c] & (got[c] == oldw[c]);
+            fresh[c] |= won;
+            pend[c] &= !won;
+            if (cas[c] & !won) {  // somebody else took the way: look at the word as it is now
+                if (low[c]) x[c] = got[c];
+                else y[c] = got[c];
+            }
+        }
+    }
+}
+
+// One scoring pass: RR x 16 candidates starting at cid[p0], RR rows per 4-lane group, every load of the pass issued
+// before the first FMA.  Loads and FMAs are unconditional (a group past the end re-reads the last candidate's row, a
+// cache hit, and discards the result): with exec-masked loads the compiler's wait-count bookkeeping has to assume
+// loads still in flight at the loop edge and drains the queue -- including the speculative adjacency fetch -- before
+// it issues the next pass.
+// Keys that a full pool would reject anyway (neighbor.h:151-153: not better than its last entry, `thr`; ~0 while the
+// pool is not full) are dropped here; the others are packed into ck[*nout ...].  `thr` is read before the hop's
+// merges, so it can only be looser than the reference's test at insert time: the merge repeats the exact test.
+// SHARED: several waves append to the same list, the cursor lives in LDS.
+struct PassProf {  // instrumented kernels only: cycles spent issuing a pass's loads, waiting + FMAs, reduction + packing
+    long long issue = 0, fma = 0, tail = 0;
+    uint32_t passes = 0;
+};
+
+template <bool IP, int NCH, bool TAIL, int RR, bool SHARED, bool PROF = false>
+__device__ __forceinline__ void score_pass(const float *__restrict__ base, uint64_t ld, const float *lq, const float4 qt,
+                                           const uint32_t *cid, u64 *ck, uint32_t p0, uint32_t m, u64 thr, uint32_t *nout,
+                                           int t, int g, PassProf *pp = nullptr) {
+    long long c0 = 0, c1 = 0;
+    if (PROF) c0 = (long long)__builtin_readcyclecounter();
+    const float4 *q4 = reinterpret_cast<const float4 *>(lq) + t;
+    uint32_t id[RR];
+    float4 x[RR][NCH];
+    float4 tl[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint32_t c = p0 + 16 * r + g;
+        id[r] = cid[c < m ? c : m - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const float4 *row = reinterpret_cast<const float4 *>(base + (u64)id[r] * ld);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) x[r][i] = row[4 * i + t];
+        if constexpr (TAIL) tl[r] = row[4 * NCH + (t & 1)];
+    }
+    // every row load of the pass is issued before the first query fragment is read or the first FMA is scheduled
+    // (left alone, the scheduler trades this batch for registers and a pass becomes several dependent round trips)
+    __builtin_amdgcn_sched_barrier(0);
+    if (PROF) {
+        c1 = (long long)__builtin_readcyclecounter();
+        pp->issue += c1 - c0;
+        c0 = c1;
+    }
+    float4 a[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) a[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const float4 y = q4[4 * i];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) acc16<IP>(a[r], x[r][i], y);
+    }
+    if (PROF) {
+        c1 = (long long)__builtin_readcyclecounter();
+        pp->fma += c1 - c0;
+        c0 = c1;
+        pp->passes++;
+    }
+    u64 key[RR], bm[RR];
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        // 16 -> 8 (distance.h:52-53 / :191-192), the 8-float step (:55-63 / :194-201), 8 -> 4 (:65-66 / :203-204), two hadd
+        float4 s1;
+        s1.x = quad_xor2(a[r].x) + a[r].x;
+        s1.y = quad_xor2(a[r].y) + a[r].y;
+        s1.z = quad_xor2(a[r].z) + a[r].z;
+        s1.w = quad_xor2(a[r].w) + a[r].w;
+        if constexpr (TAIL) acc16<IP>(s1, tl[r], qt);
+        const float e0 = quad_xor1(s1.x) + s1.x;
+        const float e1 = quad_xor1(s1.y) + s1.y;
+        const float e2 = quad_xor1(s1.z) + s1.z;
+        const float e3 = quad_xor1(s1.w) + s1.w;
+        const float rr = (e0 + e1) + (e2 + e3);
+        key[r] = make_key(IP ? -rr : rr, id[r]);
+        bm[r] = __ballot(t == 0 && p0 + 16 * r + g < m && key[r] < thr);
+        total += (uint32_t)__popcll(bm[r]);
+    }
+    if (total) {  // uniform
+        uint32_t at;
+        if constexpr (SHARED) {
+            at = 0;
+            if ((t | g) == 0) at = atomicAdd(nout, total);
+            at = uni(at);
+        } else {
+            at = *nout;
+            *nout = at + total;
+        }
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if ((bm[r] >> (4 * g + t)) & 1ull) ck[at + lanes_below(bm[r])] = key[r];
+            at += (uint32_t)__popcll(bm[r]);
+        }
+    }
+    if (PROF) pp->tail += (long long)__builtin_readcyclecounter() - c0;
+}
+
+// Score cid[0..m) against the query; keys that pass `thr` are appended to ck at *nout (see score_pass).  R x 16 rows
+// per pass while that many are left, then narrower passes for the remainder.  NCH full 16-float steps (+ the 8-float
+// step when TAIL) are known at compile time for the benchmark shapes (D = 128, 200, 512); NCH == 0 is the run-time
+// dimension.
+template <bool IP, int NCH, bool TAIL, int R, bool SHARED, bool PROF = false>
+__device__ __forceinline__ void score_rows(const float *__restrict__ base, uint64_t ld, uint32_t dim, const float *lq,
+                                           const uint32_t *cid, u64 *ck, uint32_t m, u64 thr, uint32_t *nout, int lane,
+                                           PassProf *pp = nullptr) {
+    const int t = lane & 3, g = lane >> 2;
+    if constexpr (NCH > 0) {
+        constexpr int RM = NCH > 16 ? 1 : R;  // a 512-d row is 32 float4 registers per lane
+        float4 qt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (TAIL) qt = *(reinterpret_cast<const float4 *>(lq) + 4 * NCH + (t & 1));
+        uint32_t p0 = 0;
+        if constexpr (RM >= 4)
+            for (; p0 + 48 < m; p0 += 64) score_pass<IP, NCH, TAIL, 4, SHARED, PROF>(base, ld, lq, qt, cid, ck, p0, m, thr, nout, t, g, pp);
+        if constexpr (RM >= 2)
+            for (; p0 + 16 < m; p0 += 32) score_pass<IP, NCH, TAIL, 2, SHARED, PROF>(base, ld, lq, qt, cid, ck, p0, m, thr, nout, t, g, pp);
+        for (; p0 < m; p0 += 16) score_pass<IP, NCH, TAIL, 1, SHARED, PROF>(base, ld, lq, qt, cid, ck, p0, m, thr, nout, t, g, pp);
+    } else {
+        for (uint32_t p0 = 0; p0 < m; p0 += 16) {
+            const uint32_t c = p0 + g;
+            float d = 0.f;
+            uint32_t id = 0;
+            if (c < m) {  // whole 4-lane groups are active or idle together
+                id = cid[c];
+                d = row_distance<IP, 0>(base + (u64)id * ld, lq, dim, t);
+            }
+            const u64 key = make_key(d, id);
+            const u64 bm = __ballot(t == 0 && c < m && key < thr);
+            const uint32_t total = (uint32_t)__popcll(bm);
+            if (total == 0) continue;
+            uint32_t at;
+            if constexpr (SHARED) {
+                at = 0;
+                if (lane == 0) at = atomicAdd(nout, total);
+                at = uni(at);
+            } else {
+                at = *nout;
+                *nout = at + total;
+            }
+            if ((bm >> lane) & 1ull) ck[at + lanes_below(bm)] = key;
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue, which would
+// make wave 0 sit out the round trip of its speculative adjacency fetch before the other waves may start scoring;
+// everything the waves of a query hand each other (candidate ids, keys, control words) lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of cnt <= 64 candidates when the pool (L_pq <= 64)
+// lives in a register pair of the wave: lane i holds entry i (`pk`; lanes >= psize hold ~0), candidates come from
+// ck[0..cnt).  One pass over the candidates a full pool does not reject (:151-153): a ballot of "pool entry < key"
+// is the key's lower bound (its popcount) -- no binary search; a ballot of "pool entry == key" is the reference's
+// duplicate test (:161-162); the same broadcast key ranks the other candidates and tells every pool entry whether it
+// moves up.  Entry i ends at i + #{candidates landing at or before it}, candidate c at lower_bound(c) + rank(c);
+// the scatter goes through `scratch` (the LDS pool region) and is read back one entry per lane.
+__device__ __forceinline__ void merge_regpool(u64 &pk, uint32_t &psize, const u64 *ck, uint32_t cnt, uint32_t L, u64 *scratch,
+                                              int lane) {
+    const u64 FLAG = 1ull;
+    const u64 ci = (uint32_t)lane < cnt ? ck[lane] : ~0ull;
+    bool valid = (uint32_t)lane < cnt;
+    if (psize == L) valid = valid && ci < (lane_u64(pk, (int)L - 1) & ~FLAG);
+    const u64 todo = __ballot(valid);
+    if (todo == 0) return;
+    const bool inpool = (uint32_t)lane < psize;
+    const u64 pkm = pk & ~FLAG;
+    uint32_t r = 0, shift = 0, lo_mine = 0;
+    u64 dead = 0;  // candidates found to repeat an earlier candidate's key (cannot happen within one adjacency row)
+    for (u64 it = todo; it;) {
+        const int j = __ffsll((long long)it) - 1;
+        it &= it - 1;
+        if ((dead >> j) & 1ull) continue;
+        const u64 kj = lane_u64(ci, j);
+        const u64 below = __ballot(inpool && pkm < kj);
+        if (__ballot(inpool && pkm == kj)) {  // already in the pool
+            if (lane == j) valid = false;
+            continue;
+        }
+        const u64 rep = __ballot(valid && lane > j && ci == kj);
+        dead |= rep;
+        if ((rep >> lane) & 1ull) valid = false;
+        const uint32_t lo_j = (uint32_t)__popcll(below);
+        if (lane == j) lo_mine = lo_j;
+        r += (kj < ci) ? 1u : 0u;
+        shift += (lo_j <= (uint32_t)lane) ? 1u : 0u;
+    }
+    const uint32_t s = (uint32_t)__popcll(__ballot(valid));
+    if (inpool && (uint32_t)lane + shift < L) scratch[(uint32_t)lane + shift] = pk;
+    if (valid && lo_mine + r < L) scratch[lo_mine + r] = ci;
+    psize = (psize + s < L) ? psize + s : L;
+    wave_sync();
+    pk = (uint32_t)lane < psize ? scratch[lane] : ~0ull;
+    wave_sync();
+}
+
+// ctrl words (LDS) of the multi-wave forms: 0 query, 1 candidates of the round trip (NONE = query finished),
+// 2 survivors appended by the waves, 3 pool full, 4-5 reject threshold (register-pool form)
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF>
+__device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
+    constexpr int R = 2;  // base rows per 4-lane group and scoring pass
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = (W == 1) ? 0 : (int)(threadIdx.x >> 6);
+    u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);
+    u64 *ck = reinterpret_cast<u64 *>(smem + p.off_ck);
+    uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
+    float *lq = reinterpret_cast<float *>(smem + p.off_q);
+    uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
+    volatile uint32_t *ctrl = reinterpret_cast<volatile uint32_t *>(smem + p.off_ctrl);
+    const uint32_t L = p.L;
+    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
+    uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
+    auto block_sync = [&]() {
+        if constexpr (W == 1) wave_sync();
+        else lds_barrier();
+    };
+
+    for (;;) {
+        uint32_t q = 0;
+        if constexpr (W == 1) {
+            if (lane == 0) q = atomicAdd(p.counter, 1u);
+            q = uni(q);
+        } else {
+            if (threadIdx.x == 0) ctrl[0] = atomicAdd(p.counter, 1u);
+            lds_barrier();
+            q = ctrl[0];
+        }
+        if (q >= p.nq) break;
+        long long tq0 = 0, t_adj = 0, t_filter = 0, t_score = 0, t_merge = 0, t_sel = 0;
+        uint32_t pf_hit = 0, n_rt = 0, n_surv = 0;
+        PassProf pprof;
+        if (PROF) tq0 = (long long)__builtin_readcyclecounter();
+
+        // query -> LDS (tests/test_search_roargraph.cpp:205 passes aligned_query_data + i * q_dim)
+        const float *qp = p.queries + (u64)q * p.qstride;
+        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
+            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        if (MODE == VIS_LDS) {  // fresh visited table
+            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
+            for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
+        } else {  // VisitedList::reset (visited_list_pool.h:20-26) with a u8 epoch
+            epoch++;
+            if (epoch == 256u) {
+                for (u64 i = (u64)threadIdx.x * 16; i < p.tag_stride; i += 1024 * W)
+                    *reinterpret_cast<uint4 *>(tags + i) = make_uint4(0, 0, 0, 0);
+                __threadfence();
+                epoch = 1;
+            }
+        }
+        block_sync();
+
+        // state of the sequential part (wave 0).  Pool: `pk` (register form, L_pq <= 64) or pool[] in LDS with the
+        // cursor `cur` = index of the closest unexpanded entry.
+        u64 pk = ~0ull;
+        uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
+        const uint32_t *arow = p.adj;
+        if (wid == 0) {
+            // the entry point is always the first expansion: its adjacency row travels with its base row
+            arow = p.adj + (u64)p.ep * p.adj_stride;
+            a0 = arow[lane];
+            a1 = arow[64 + lane];
+            a2 = arow[128 + lane];
+            pf = p.ep;
+            // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
+            if (lane == 0) cid[0] = p.ep;
+            wave_sync();
+            uint32_t one = 0;
+            score_rows<IP, NCH, TAIL, 1, false>(p.base, p.ld, p.dim, lq, cid, ck, 1, ~0ull, &one, lane);
+            wave_sync();
+            if constexpr (RP) {
+                if (lane == 0) pk = ck[0];
+            } else {
+                if (lane == 0) pool[0] = ck[0];
+            }
+            wave_sync();
+        }
+
+        for (;;) {
+            uint32_t m = 0;
+            bool done = false;
+            if (wid == 0) {
+                long long c0 = 0, c1 = 0;
+                if (PROF) c0 = (long long)__builtin_readcyclecounter();
+                uint32_t nextv = NONE;  // closest unexpanded entry once the current one is flagged (prefetch target)
+                if (wpos > deg) {
+                    // closest_unexpanded (neighbor.h:185-192): flag the entry, the cursor moves past flagged ones
+                    uint32_t v = 0;
+                    if constexpr (RP) {
+                        const u64 um = __ballot((uint32_t)lane < psize && !(pk & 1ull));
+                        if (um == 0) {  // !has_unexpanded_node, :2356
+                            done = true;
+                        } else {
+                            const int c = __ffsll((long long)um) - 1;
+                            v = (uint32_t)lane_u64(pk, c) >> 1;
+                            if (lane == c) pk |= 1ull;
+                            const u64 rest = um & (um - 1);
+                            if (rest) nextv = (uint32_t)lane_u64(pk, __ffsll((long long)rest) - 1) >> 1;
+                        }
+                    } else {
+                        if (cur >= psize) {
+                            done = true;
+                        } else {
+                            const u64 e = pool[cur];
+                            v = (uint32_t)e >> 1;
+                            if (lane == 0) pool[cur] = e | 1ull;
+                            wave_sync();
+                            uint32_t found = psize;
+                            for (uint32_t c = cur + 1; c < psize; c += 64) {
+                                const uint32_t kidx = c + (uint32_t)lane;
+                                const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                                const u64 b = __ballot(unf);
+                                if (b) {
+                                    found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                                    break;
+                                }
+                            }
+                            cur = found;
+                        }
+                    }
+                    if (!done) {
+                        ++hops;
+                        if (PROF) {
+                            c1 = (long long)__builtin_readcyclecounter();
+                            t_sel += c1 - c0;
+                            c0 = c1;
+                        }
+                        // adjacency row: word 0 = degree, word w (>= 1) = neighbour w - 1
+                        arow = p.adj + (u64)v * p.adj_stride;
+                        vcur = v;
+                        if (v != pf) {  // the speculative fetch went to another row: pay the round trip now
+                            a0 = arow[lane];
+                            a1 = arow[64 + lane];
+                            a2 = arow[128 + lane];
+                            if (PROF) n_rt++;
+                        } else if (PROF) {
+                            pf_hit++;
+                        }
+                        deg = uni(a0);
+                        scanned += deg;
+                        wpos = 0;
+                    }
+                } else if constexpr (RP) {  // a row longer than 191 entries continues (its next words are already here)
+                    const u64 um = __ballot((uint32_t)lane < psize && !(pk & 1ull));
+                    if (um) nextv = (uint32_t)lane_u64(pk, __ffsll((long long)um) - 1) >> 1;
+                }
+                if (!done) {
+                    // visited filter over the whole round trip (index_bipartite.cpp:2378-2385), survivors packed in cid
+                    uint32_t nb[3];
+                    bool isn[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t w = wpos + 64u * (uint32_t)c + (uint32_t)lane;
+                        isn[c] = w >= 1 && w <= deg;
+                        nb[c] = isn[c] ? (c == 0 ? a0 : c == 1 ? a1 : a2) : 0u;
+                    }
+                    if (PROF) {
+                        c1 = (long long)__builtin_readcyclecounter();
+                        t_adj += c1 - c0;
+                        c0 = c1;
+                    }
+                    bool fresh[3];
+                    if (MODE == VIS_EXACT) {  // visited_array[nbr] != tag ... = tag  (:2378,2385)
+                        uint32_t tg[3] = {0, 0, 0};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (isn[c]) tg[c] = __builtin_nontemporal_load(tags + nb[c]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            fresh[c] = isn[c] && tg[c] != epoch;
+                            if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
+                        }
+                    } else {
+                        visited_lds3(isn, nb, vis, sets_mask, p.vis_sets_log2, fresh);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const u64 fm = __ballot(fresh[c]);
+                        if (fresh[c]) cid[m + lanes_below(fm)] = nb[c];
+                        m += (uint32_t)__popcll(fm);
+                    }
+                    wpos += 192u;
+                    cmps += m;  // ++cmps per scored neighbour, :2397
+                    // Next adjacency words, in flight while this round trip's rows are scored: the rest of this row
+                    // if it is longer, else the row of the closest unexpanded entry as the pool stands now -- if this
+                    // hop's merges put something in front of it the fetch is simply dropped (pf is compared at select).
+                    {
+                        const uint32_t *nrow = arow + wpos;
+                        if (wpos > deg) {
+                            if constexpr (RP) pf = (nextv != NONE) ? nextv : vcur;  // (nothing left: any valid row)
+                            else pf = (cur < psize) ? (uint32_t)pool[cur] >> 1 : vcur;
+                            nrow = p.adj + (u64)pf * p.adj_stride;
+                        }
+                        a0 = nrow[lane];
+                        a1 = nrow[64 + lane];
+                        a2 = nrow[128 + lane];
+                    }
+                    if (PROF) {
+                        c1 = (long long)__builtin_readcyclecounter();
+                        t_filter += c1 - c0;
+                    }
+                }
+                if (W > 1 && lane == 0) {
+                    ctrl[1] = done ? NONE : m;
+                    ctrl[2] = 0;
+                    ctrl[3] = (psize == L) ? 1u : 0u;
+                    if constexpr (RP) {
+                        const u64 last = lane_u64(pk, (int)L - 1) & ~1ull;  // (lane 0 only reads the broadcast)
+                        ctrl[4] = (uint32_t)last;
+                        ctrl[5] = (uint32_t)(last >> 32);
+                    }
+                }
+            }
+            long long s0 = 0;
+            if (PROF) s0 = (long long)__builtin_readcyclecounter();
+            uint32_t nsurv = 0;
+            if constexpr (W > 1) {
+                lds_barrier();
+                m = ctrl[1];
+                if (m == NONE) break;
+                if (m) {  // even split in units of 16 rows
+                    u64 thr = ~0ull;
+                    if (ctrl[3]) thr = RP ? (((u64)ctrl[5] << 32) | ctrl[4]) : (pool[L - 1] & ~1ull);
+                    const uint32_t per = (((m + W - 1) / W) + 15u) & ~15u;
+                    const uint32_t lo = (uint32_t)wid * per;
+                    if (lo < m)
+                        score_rows<IP, NCH, TAIL, R, true, PROF>(p.base, p.ld, p.dim, lq, cid + lo, ck, (m - lo < per) ? m - lo : per,
+                                                                 thr, const_cast<uint32_t *>(ctrl + 2), lane, &pprof);
+                }
+                lds_barrier();
+                nsurv = ctrl[2];
+            } else {
+                if (done) break;
+                wave_sync();
+                if (m) {
+                    u64 thr = ~0ull;
+                    if (psize == L) thr = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
+                    score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid, ck, m, thr, &nsurv, lane, &pprof);
+                }
+                wave_sync();
+            }
+            if (PROF && wid == 0) {
+                const long long s1 = (long long)__builtin_readcyclecounter();
+                t_score += s1 - s0;
+                s0 = s1;
+            }
+            if (wid == 0) {
+                if (PROF) n_surv += nsurv;
+                for (uint32_t b = 0; b < nsurv; b += 64) {
+                    const uint32_t cnt = (nsurv - b < 64u) ? nsurv - b : 64u;
+                    if constexpr (RP) merge_regpool(pk, psize, ck + b, cnt, L, pool, lane);
+                    else merge_candidates(pool, ck + b, cnt, L, psize, cur, lane);
+                }
+                if (PROF) t_merge += (long long)__builtin_readcyclecounter() - s0;
+            }
+        }
+
+        // results (:2408-2418); a short pool is reported, not thrown
+        if (wid == 0) {
+            for (uint32_t i = lane; i < p.k; i += 64) {
+                uint32_t id = 0xFFFFFFFFu;
+                float d = __builtin_inff();
+                if (i < psize) {
+                    const u64 e = RP ? pk : pool[i];
+                    id = (uint32_t)e >> 1;
+                    d = ord2f((uint32_t)(e >> 32));
+                }
+                p.out_ids[(u64)q * p.k + i] = id;
+                p.out_dists[(u64)q * p.k + i] = d;
+            }
+            if (lane == 0) {
+                if (p.out_cmps) p.out_cmps[q] = cmps;
+                if (p.out_hops) p.out_hops[q] = hops;
+                if (p.out_scanned) p.out_scanned[q] = scanned;
+                if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+                if (PROF && p.prof) {
+                    unsigned long long *o = p.prof + (u64)q * 16;
+                    o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);
+                    o[1] = (unsigned long long)t_sel;
+                    o[2] = (unsigned long long)t_adj;
+                    o[3] = (unsigned long long)t_filter;
+                    o[4] = (unsigned long long)t_score;
+                    o[5] = (unsigned long long)t_merge;
+                    o[6] = pf_hit;
+                    o[7] = n_rt;
+                    o[8] = (unsigned long long)pprof.issue;
+                    o[9] = (unsigned long long)pprof.fma;
+                    o[10] = (unsigned long long)pprof.tail;
+                    o[11] = pprof.passes;
+                    o[12] = n_surv;
+                    o[13] = o[14] = o[15] = 0;
+                }
+            }
+        }
+        block_sync();
+    }
+    if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
+}
+
+// Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of
+// a scoring pass for an occupancy the LDS footprint does not allow anyway).
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))
+roar_search_v2_kernel(const RoarSearchParams p) {
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF>(p);
+}
+
+// The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
+// query), so that a kernel trace of a process that builds and then serves keeps the two apart.
+template <bool IP, int NCH, bool TAIL, bool RP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+roar_build_search_v2_kernel(const RoarSearchParams p) {
+    search_v2<VIS_LDS, IP, NCH, TAIL, 1, RP, false>(p);
+}
+
+template <int MODE, bool IP, int NCH, bool TAIL>
+const void *pick_form(const RoarKernelSel &s) {
+    const bool rp = s.regpool != 0;
+    if (s.form == ROAR_FORM_BUILDER) {
+        if constexpr (MODE == VIS_LDS)
+            return rp ? (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, true>
+                      : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
+        else
+            return nullptr;
+    }
+    if (s.prof) {  // instrumented instantiations exist for the Text-to-Image shape only
+        if constexpr (IP && NCH == 12) {
+            if (s.waves == 4)
+                return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, true, true>
+                          : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, false, true>;
+            if (s.waves == 2)
+                return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, true, true>
+                          : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, false, true>;
+            return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, true>
+                      : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true>;
+        } else {
+            return nullptr;
+        }
+    }
+    if (s.waves == 4)
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, true, false>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, false, false>;
+    if (s.waves == 2)
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, true, false>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, false, false>;
+    return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false>
+              : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false>;
+}
+
+}  // namespace
+
+// One of these per translation unit (visited mode x metric): kernel address for a selection, or null.
+#define ROAR_PICK_NAME2(m, i) roar_pick_search_##m##_##i
+#define ROAR_PICK_NAME(m, i) ROAR_PICK_NAME2(m, i)
+extern "C" const void *ROAR_PICK_NAME(ROAR_TU_MODE, ROAR_TU_IP)(const RoarKernelSel *s, uint32_t dim) {
+    constexpr int MODE = ROAR_TU_MODE;
+    constexpr bool IP = ROAR_TU_IP != 0;
+    switch (dim) {
+        case 128: return pick_form<MODE, IP, 8, false>(*s);   // SIFT shape
+        case 200: return pick_form<MODE, IP, 12, true>(*s);   // Text-to-Image shape
+        case 512: return pick_form<MODE, IP, 32, false>(*s);  // WebVid shape
+        default: return pick_form<MODE, IP, 0, false>(*s);    // any other length: the row is walked at run time
+    }
+}

@@ -1,0 +1,340 @@
+// roar_wave.h -- wave64 building blocks shared by the gfx950 kernels of the RoarGraph beam search
+// (roar_search_v2.h, roar_kernels.hip): cross-lane helpers, the order-preserving key, the reference's
+// distance reduction tree, the sorted-pool merge and the visited-set filters.
+//
+//   reference (CPU)                                   here (per wave)
+//   ------------------------------------------------  ---------------------------------------------
+//   NeighborPriorityQueue  neighbor.h:138-223         sorted u64 keys  (ord(dist)<<32 | id<<1 | expanded)
+//   VisitedList            visited_list_pool.h:8-29   LDS 4-way u16 tag table (mode LDS) or u8 epoch tags in HBM (mode EXACT)
+//   distance_->compare     distance.h:39-89,179-223   4 lanes per row, 64-B pieces, fmaf chains, quad-DPP reduction tree
+//
+// Distances are bit-identical to the reference's AVX-512 code as gcc builds it (-Ofast contracts
+// every mul+add to vfmadd231ps): lane t of a 4-lane group holds SIMD lanes 4t..4t+3 of the
+// reference's zmm accumulator and walks the row in the same 16-float steps, then the
+// 16->8->4->hadd reduction tree is replayed with quad DPP moves.  Bit-identical distances make the
+// (distance, id) order, hence every expansion and every returned id, identical to the CPU path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "roar_device.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+// LDS traffic between lanes of one wave: the LDS executes a wave's instructions in order, the
+// fences only stop the compiler from reordering across the hand-off.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 lane_u64(u64 v, int l) {
+    uint32_t lo = lane_u32((uint32_t)v, l), hi = lane_u32((uint32_t)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t lanes_below(u64 mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// float <-> order-preserving u32 (so that one u64 compare is Neighbor::operator<, neighbor.h:29-31)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    if (f == 0.0f) f = 0.0f;  // -0.0 == +0.0 for operator<
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o >> 31) ? (o ^ 0x80000000u) : ~o);
+}
+__device__ __forceinline__ u64 make_key(float d, uint32_t id) { return ((u64)f2ord(d) << 32) | ((u64)id << 1); }
+
+// quad DPP: value of lane (l ^ 2) / (l ^ 1) inside each 4-lane group
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+template <bool IP>
+__device__ __forceinline__ void acc16(float4 &acc, const float4 x, const float4 y) {
+    if (IP) {  // distance.h:187  msum0 += mx * my  (fma)
+        acc.x = __builtin_fmaf(x.x, y.x, acc.x);
+        acc.y = __builtin_fmaf(x.y, y.y, acc.y);
+        acc.z = __builtin_fmaf(x.z, y.z, acc.z);
+        acc.w = __builtin_fmaf(x.w, y.w, acc.w);
+    } else {  // distance.h:47-48  d = mx - my; msum0 += d * d
+        float a = x.x - y.x, b = x.y - y.y, c = x.z - y.z, d = x.w - y.w;
+        acc.x = __builtin_fmaf(a, a, acc.x);
+        acc.y = __builtin_fmaf(b, b, acc.y);
+        acc.z = __builtin_fmaf(c, c, acc.z);
+        acc.w = __builtin_fmaf(d, d, acc.w);
+    }
+}
+
+// One base row against the query held in LDS, by the 4 lanes of a group (t = lane & 3).
+// NCH > 0: number of full 16-float steps known at compile time (all loads issued up front);
+// NCH == 0: runtime dim, 8 steps in flight at a time.
+template <bool IP, int NCH>
+__device__ __forceinline__ float row_distance(const float *__restrict__ rowp, const float *lq, uint32_t dim, int t) {
+    const float4 *row = reinterpret_cast<const float4 *>(rowp) + t;
+    const float4 *q4 = reinterpret_cast<const float4 *>(lq) + t;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t done;
+    if (NCH > 0) {
+        float4 x[NCH > 0 ? NCH : 1];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) x[i] = row[4 * i];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) acc16<IP>(acc, x[i], q4[4 * i]);
+        done = NCH;
+    } else {
+        const uint32_t nfull = dim >> 4;
+        uint32_t c = 0;
+        for (; c + 8 <= nfull; c += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = row[4 * (c + i)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc16<IP>(acc, x[i], q4[4 * (c + i)]);
+        }
+        for (; c < nfull; ++c) acc16<IP>(acc, row[4 * c], q4[4 * c]);
+        done = nfull;
+    }
+    // 16 -> 8 (distance.h:52-53 / :191-192): lanes t and t^2 now both hold s1[4*(t&1) .. +3]
+    float4 s1;
+    s1.x = quad_xor2(acc.x) + acc.x;
+    s1.y = quad_xor2(acc.y) + acc.y;
+    s1.z = quad_xor2(acc.z) + acc.z;
+    s1.w = quad_xor2(acc.w) + acc.w;
+    if (dim & 8) {  // one 8-float step (distance.h:55-63 / :194-201)
+        const float4 *rt = reinterpret_cast<const float4 *>(rowp) + 4 * done + (t & 1);
+        const float4 *qt = reinterpret_cast<const float4 *>(lq) + 4 * done + (t & 1);
+        acc16<IP>(s1, *rt, *qt);
+    }
+    // 8 -> 4 (:65-66 / :203-204), then the two hadd (:85-86 / :221-222)
+    float a = quad_xor1(s1.x) + s1.x;
+    float b = quad_xor1(s1.y) + s1.y;
+    float c2 = quad_xor1(s1.z) + s1.z;
+    float d = quad_xor1(s1.w) + s1.w;
+    float r = (a + b) + (c2 + d);
+    return IP ? -r : r;  // distance.h:223
+}
+
+// Tail of row_distance shared by the one-row and two-row forms: 16 -> 8 -> (8-float step) -> 4 -> hadd.
+template <bool IP>
+__device__ __forceinline__ float reduce_row(float4 acc, const float *__restrict__ rowp, const float *lq, uint32_t dim,
+                                            uint32_t done, int t) {
+    float4 s1;
+    s1.x = quad_xor2(acc.x) + acc.x;
+    s1.y = quad_xor2(acc.y) + acc.y;
+    s1.z = quad_xor2(acc.z) + acc.z;
+    s1.w = quad_xor2(acc.w) + acc.w;
+    if (dim & 8) {
+        const float4 *rt = reinterpret_cast<const float4 *>(rowp) + 4 * done + (t & 1);
+        const float4 *qt = reinterpret_cast<const float4 *>(lq) + 4 * done + (t & 1);
+        acc16<IP>(s1, *rt, *qt);
+    }
+    float a = quad_xor1(s1.x) + s1.x;
+    float b = quad_xor1(s1.y) + s1.y;
+    float c2 = quad_xor1(s1.z) + s1.z;
+    float d = quad_xor1(s1.w) + s1.w;
+    float r = (a + b) + (c2 + d);
+    return IP ? -r : r;
+}
+
+// Score cid[0..m) against the query; ck[i] = key(distance, id).  16 rows per pass; with a
+// compile-time row length two passes (32 rows) are in flight at once: every load of both rows is
+// issued before the first FMA, the query fragments are read from LDS once for the pair.
+template <bool IP, int NCH>
+__device__ __forceinline__ void score_candidates(const float *__restrict__ base, uint64_t ld, uint32_t dim,
+                                                 const float *lq, const uint32_t *cid, u64 *ck, uint32_t m,
+                                                 int lane) {
+    const int t = lane & 3, g = lane >> 2;
+    uint32_t p0 = 0;
+    if (NCH > 0) {
+        for (; p0 + 16 < m; p0 += 32) {
+            const uint32_t c0 = p0 + g, c1 = p0 + 16 + g;  // c0 < m always here
+            const bool has1 = c1 < m;
+            const uint32_t id0 = cid[c0];
+            const uint32_t id1 = has1 ? cid[c1] : id0;
+            const float *r0 = base + (u64)id0 * ld, *r1 = base + (u64)id1 * ld;
+            const float4 *row0 = reinterpret_cast<const float4 *>(r0) + t;
+            const float4 *row1 = reinterpret_cast<const float4 *>(r1) + t;
+            const float4 *q4 = reinterpret_cast<const float4 *>(lq) + t;
+            float4 x0[NCH > 0 ? NCH : 1], x1[NCH > 0 ? NCH : 1];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) x0[i] = row0[4 * i];
+            if (has1) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) x1[i] = row1[4 * i];
+            }
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 y = q4[4 * i];
+                acc16<IP>(a0, x0[i], y);
+                if (has1) acc16<IP>(a1, x1[i], y);
+            }
+            const float d0 = reduce_row<IP>(a0, r0, lq, dim, NCH, t);
+            if (t == 0) ck[c0] = make_key(d0, id0);
+            if (has1) {
+                const float d1 = reduce_row<IP>(a1, r1, lq, dim, NCH, t);
+                if (t == 0) ck[c1] = make_key(d1, id1);
+            }
+        }
+    }
+    for (; p0 < m; p0 += 16) {
+        const uint32_t c = p0 + g;
+        if (c < m) {  // whole 4-lane groups are active or idle together
+            const uint32_t id = cid[c];
+            const float d = row_distance<IP, NCH>(base + (u64)id * ld, lq, dim, t);
+            if (t == 0) ck[c] = make_key(d, id);
+        }
+    }
+}
+
+// NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of m <= 64 candidates at once.
+// Sequential inserts keep the top-L of everything seen; so does this merge, entry for entry.
+// Duplicate (distance, id) pairs are dropped exactly as the binary-search probe does (:161-162).
+__device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m, uint32_t L, uint32_t &psize,
+                                                 uint32_t &cur, int lane) {
+    const u64 FLAG = 1ull;
+    bool valid = (uint32_t)lane < m;
+    u64 key = valid ? ck[lane] : ~0ull;
+    if (psize == L) {  // neighbor.h:151-153
+        const u64 last = pool[L - 1] & ~FLAG;
+        valid = valid && key < last;
+    }
+    if (__ballot(valid) == 0) return;
+    // lower bound of key among the (flag-masked) pool keys
+    uint32_t lo = 0;
+    {
+        uint32_t len = psize;
+        const int iters = 32 - __builtin_clz(psize);  // psize >= 1
+        for (int it = 0; it < iters; ++it) {
+            if (len > 0) {
+                const uint32_t half = len >> 1, mid = lo + half;
+                const bool less = (pool[mid] & ~FLAG) < key;
+                lo = less ? mid + 1 : lo;
+                len = less ? len - half - 1 : half;
+            }
+        }
+    }
+    if (valid && lo < psize && (pool[lo] & ~FLAG) == key) valid = false;  // already in the pool
+    // rank among the surviving candidates; a later lane with an equal key is a duplicate
+    uint32_t r = 0;
+    for (u64 it = __ballot(valid); it;) {
+        const int j = __ffsll((long long)it) - 1;
+        it &= it - 1;
+        if (!((__ballot(valid) >> j) & 1)) continue;
+        const u64 kj = lane_u64(key, j);
+        if (valid && j != lane) {
+            if (kj < key) r++;
+            else if (kj == key && j < lane) valid = false;
+        }
+    }
+    const u64 vm = __ballot(valid);
+    if (vm == 0) return;
+    const uint32_t s = (uint32_t)__popcll(vm);
+    const int l0 = __ffsll((long long)__ballot(valid && r == 0)) - 1;
+    const uint32_t pmin = lane_u32(lo, l0);
+    // Shift pool[pmin, psize) right: the entry at index i moves up by the number of survivors whose lower bound
+    // is <= i.  64-entry chunks, top chunk first, four chunks read before the first is written back: the LDS executes
+    // a wave's instructions in order, a lower chunk's reads never overlap an upper chunk's (higher) write range, and
+    // a lower chunk's writes come after the upper chunk's reads in program order -- so no wait is needed in between.
+    const uint32_t slo = valid ? lo : 0xFFFFFFFFu;
+    for (uint32_t hi = psize; hi > pmin;) {
+        u64 e[4];
+        uint32_t dst[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            act[u] = false;
+            e[u] = 0ull;
+            dst[u] = 0u;
+            if (hi > pmin) {  // uniform
+                const uint32_t lo_c = (hi - pmin > 64u) ? hi - 64u : pmin;
+                const uint32_t kidx = lo_c + (uint32_t)lane;
+                const bool a = kidx < hi;
+                if (a) e[u] = pool[kidx];
+                uint32_t shift = (uint32_t)__popcll(__ballot(slo <= lo_c));
+                for (u64 it = __ballot(slo > lo_c && slo < hi); it;) {  // survivors landing inside this chunk
+                    const int j = __ffsll((long long)it) - 1;
+                    it &= it - 1;
+                    shift += (lane_u32(slo, j) <= kidx) ? 1u : 0u;
+                }
+                dst[u] = kidx + shift;
+                act[u] = a && dst[u] < L;
+                hi = lo_c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (act[u]) pool[dst[u]] = e[u];
+    }
+    wave_sync();
+    if (valid && lo + r < L) pool[lo + r] = key;
+    psize = (psize + s < L) ? psize + s : L;
+    cur = cur < pmin ? cur : pmin;  // neighbor.h:180-182
+    wave_sync();
+}
+
+constexpr int VIS_EXACT = 0;
+constexpr int VIS_LDS = 1;
+
+// visited test-and-set for one adjacency chunk (lane = one neighbour); returns "not visited before".
+template <int MODE>
+__device__ __forceinline__ bool visited_filter(bool isnbr, uint32_t nb, uint16_t *vis, uint32_t sets_mask,
+                                               uint32_t sets_log2, uint8_t *tags, uint32_t epoch) {
+    bool fresh;
+    if (MODE == VIS_LDS) {
+        // 4-way set of u16 tags; (set, tag) <-> id is a bijection, so a hit is never false.
+        // The table may forget (way overwritten): the node is then scored again and the
+        // duplicate key is dropped by the merge, results are unchanged.
+        const uint32_t set = nb & sets_mask;
+        const uint32_t tag = (nb >> sets_log2) + 1u;
+        const uint2 ww = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+        const uint32_t t0 = ww.x & 0xFFFFu, t1 = ww.x >> 16, t2 = ww.y & 0xFFFFu, t3 = ww.y >> 16;
+        const bool hit = (t0 == tag) | (t1 == tag) | (t2 == tag) | (t3 == tag);
+        fresh = isnbr && !hit;
+        // Insert.  Lanes of this instruction that share a set race for the same empty
+        // way, so a write into an empty way is verified on the next round and retried
+        // by the loser; a full set overwrites a victim way without verification (that is
+        // the only place the table forgets).
+        bool pending = fresh;
+        uint32_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
+        while (__ballot(pending)) {
+            if (pending) {
+                const bool present = (a0 == tag) | (a1 == tag) | (a2 == tag) | (a3 == tag);
+                const bool full = (a0 != 0) & (a1 != 0) & (a2 != 0) & (a3 != 0);
+                if (present) {
+                    pending = false;
+                } else {
+                    const uint32_t way = a0 == 0 ? 0u : a1 == 0 ? 1u : a2 == 0 ? 2u : a3 == 0 ? 3u : (tag & 3u);
+                    vis[4 * set + way] = (uint16_t)tag;
+                    if (full) pending = false;
+                }
+            }
+            wave_sync();
+            if (pending) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(vis + 4 * set);
+                a0 = w2.x & 0xFFFFu, a1 = w2.x >> 16, a2 = w2.y & 0xFFFFu, a3 = w2.y >> 16;
+            }
+            wave_sync();
+        }
+    } else {  // visited_array[nbr] != tag ... = tag  (index_bipartite.cpp:2378,2385)
+        uint32_t tg = 0;
+        if (isnbr) tg = __builtin_nontemporal_load(tags + nb);
+        fresh = isnbr && tg != epoch;
+        if (fresh) __builtin_nontemporal_store((uint8_t)epoch, tags + nb);
+    }
+    return fresh;
+}
+
+
+}  // namespace

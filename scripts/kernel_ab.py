@@ -1,6 +1,7 @@
-"""A/B of the search kernels on the T2I shape (bench.py's graph): kernel time per (kernel generation, waves per query,
-rows per pass, batch size, L_pq, visited mode), ids / distances / hops checked against the first-generation EXACT run,
-and the phase timers of the instrumented kernel.  Output: gpurun_out/kernel_ab.txt"""
+"""Kernel forms of the SearchRoarGraph kernel on the T2I shape (bench.py's graph): kernel time per (waves per query,
+pool form, batch size, L_pq, visited mode), ids / distances / hops checked against the EXACT one-wave run (whose cmps /
+scanned are the reference algorithm's counters), TB/s in reference-algorithm bytes, and the phase timers of the
+instrumented kernel.  Output: gpurun_out/kernel_ab.txt"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +10,7 @@ from mysteryann_amd import index as mi, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--out", default="gpurun_out/kernel_ab.txt")
-ap.add_argument("--Ls", type=int, nargs="+", default=[30, 100, 500, 2000])
+ap.add_argument("--Ls", type=int, nargs="+", default=[30, 100, 300, 500, 1000, 2000])
 ap.add_argument("--nqs", type=int, nargs="+", default=[256, 1250, 2500, 10000])
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
@@ -21,9 +22,9 @@ idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
 t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn
 say(f"# n={n} index built in {time.time() - t0:.1f}s avg degree {idx.info('nedges') / n:.1f} max {idx.info('max_degree')}")
 
-def run(nq, L, ver, kern, rows, vis, reps=4):
-    idx.set_option("kernel_version", ver); idx.set_option("search_kernel", kern); idx.set_option("score_rows", rows)
-    idx.set_option("visited_mode", vis)
+def run(nq, L, kern, vis, reps=3, ve=0, pool=0):
+    idx.set_option("search_kernel", kern); idx.set_option("visited_mode", vis); idx.set_option("vis_entries", ve)
+    idx.set_option("pool_form", pool)
     q = queries[:nq].contiguous()
     best = 1e9
     for _ in range(reps):
@@ -34,31 +35,35 @@ def run(nq, L, ver, kern, rows, vis, reps=4):
 
 for L in args.Ls:
     for nq in args.nqs:
-        ref, t_ref = run(nq, L, 1, 1, 0, 0, reps=2)  # first generation, one wave, EXACT: the reference counters
+        ref, t_ref = run(nq, L, 1, 0, reps=2)
         bytes_q = (800.0 * ref["cmps"].double().sum() + 4 * ref["scanned"].double().sum() + 8 * ref["hops"].double().sum()).item() + 880.0 * nq
-        for vis in ((1, 0) if L < 1000 else (0,)):
-            for ver, kern, rows in ((1, 1, 0), (1, 0, 0), (2, 1, 2), (2, 1, 4), (2, 3, 2), (2, 3, 4), (2, 2, 2), (2, 0, 0)):
-                if kern in (2, 3) and nq > 2500: continue
-                out, ms = run(nq, L, ver, kern, rows, vis)
-                ok = bool((out["ids"] == ref["ids"]).all() and (out["dists"] == ref["dists"]).all() and (out["hops"] == ref["hops"]).all())
-                if vis == 0: ok = ok and bool((out["cmps"] == ref["cmps"]).all() and (out["scanned"] == ref["scanned"]).all())
-                say(f"L={L:5d} nq={nq:6d} vis={'lds' if vis else 'exact'} v{ver} kern={kern} rows={rows} -> waves/q {idx.info('last_waves_per_query')} "
-                    f"grid {idx.info('last_grid'):5d} {ms:8.3f} ms {nq / ms * 1e3:10.0f} qps {bytes_q / ms / 1e9:6.2f} TB/s(ref bytes) "
-                    f"cmps {float(out['cmps'].float().mean()):.0f} same={ok}")
+        cfgs = [(1, 0, 0, 0), (0, 0, 0, 0)]                       # EXACT: one wave, auto
+        if L < 1000:
+            cfgs += [(1, 1, 0, 0), (0, 1, 0, 0)]                  # LDS table: one wave, auto
+            if nq <= 2500: cfgs += [(3, 1, 0, 0), (2, 1, 0, 0)]   # two / four waves
+            if L <= 64: cfgs += [(1, 1, 0, 1)]                    # LDS pool instead of the register pool
+            if L >= 100: cfgs += [(1, 1, 16384, 0), (1, 1, 32768, 0)]
+        for kern, vis, ve, pool in cfgs:
+            out, ms = run(nq, L, kern, vis, ve=ve, pool=pool)
+            ok = bool((out["ids"] == ref["ids"]).all() and (out["dists"] == ref["dists"]).all() and (out["hops"] == ref["hops"]).all())
+            if vis == 0: ok = ok and bool((out["cmps"] == ref["cmps"]).all() and (out["scanned"] == ref["scanned"]).all())
+            say(f"L={L:5d} nq={nq:6d} vis={'lds' if vis else 'exact'} kern={kern} ve={ve} pool={pool} -> W {idx.info('last_waves_per_query')} "
+                f"grid {idx.info('last_grid'):5d} lds {idx.info('last_lds_bytes'):6d} {ms:8.3f} ms {nq / ms * 1e3:10.0f} qps "
+                f"{bytes_q / ms / 1e9:6.2f} TB/s(ref bytes) cmps {float(out['cmps'].float().mean()):.0f} same={ok}")
 
-# phase timers (instrumented v2)
+names = ["select", "adj", "filter", "score", "merge"]
 idx.set_option("profile_phases", 1)
 for L, vis in ((30, 1), (100, 1), (500, 1), (500, 0), (2000, 0)):
     for nq in (1, 1250, 10000):
-        for kern in (1, 3):
-            if kern == 3 and nq > 2500: continue
-            out, ms = run(nq, L, 2, kern, 2, vis, reps=2)
-            pr = idx.LastProfile(nq).astype(np.float64)
-            tot = pr[:, 0].sum()
-            say(f"PROF L={L} nq={nq} vis={'lds' if vis else 'exact'} kern={kern}: {ms:.3f} ms; cycles/query {pr[:, 0].mean():.0f}; "
-                f"select {pr[:, 1].sum() / tot:.3f} adjacency {pr[:, 2].sum() / tot:.3f} filter {pr[:, 3].sum() / tot:.3f} "
-                f"score {pr[:, 4].sum() / tot:.3f} merge {pr[:, 5].sum() / tot:.3f}; spec hits {pr[:, 6].sum() / max(out['hops'].sum().item(), 1):.3f} "
-                f"adj round trips/hop {pr[:, 7].sum() / max(out['hops'].sum().item(), 1):.3f} hops {out['hops'].float().mean():.1f}")
+        out, ms = run(nq, L, 1, vis, reps=2)
+        pr = idx.LastProfile(nq).astype(np.float64)
+        H = out["hops"].double().sum().item()
+        ph = " ".join(f"{nm} {pr[:, 1 + i].sum() / H:7.0f}" for i, nm in enumerate(names))
+        say(f"PROF L={L} nq={nq} vis={'lds' if vis else 'exact'} W=1: {ms:.3f} ms; cycles/hop {pr[:, 0].sum() / H:7.0f}: {ph} | per pass: "
+            f"issue {pr[:, 8].sum() / max(pr[:, 11].sum(), 1):6.0f} wait+fma {pr[:, 9].sum() / max(pr[:, 11].sum(), 1):6.0f} "
+            f"tail {pr[:, 10].sum() / max(pr[:, 11].sum(), 1):6.0f}, passes/hop {pr[:, 11].sum() / H:.2f} rows/hop "
+            f"{out['cmps'].double().sum().item() / H:.1f} survivors/hop {pr[:, 12].sum() / H:.1f} spec hit {pr[:, 6].sum() / H:.2f} "
+            f"query cycles mean {pr[:, 0].mean():.0f} max {pr[:, 0].max():.0f}")
 idx.set_option("profile_phases", 0)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
 open(args.out, "w").write("\n".join(lines) + "\n")

@@ -519,6 +519,52 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
     assert idx.info("last_waves_per_query") == 4  # 24 queries are resident as 4-wave workgroups
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+@pytest.mark.parametrize("pool_form", [0, 1], ids=["regpool", "ldspool"])
+def test_every_kernel_form_matches_reference_golden(mode, pool_form, golden_dir, built_lib):
+    """One / two / four waves per query x candidate pool in registers (L_pq <= 64) or in LDS x visited mode: all of
+    them are the same algorithm and must reproduce the reference's goldens bit for bit (ids, dists, hops, scanned,
+    cmps).  pool_form = 1 forces the LDS pool below L_pq = 64 as well."""
+    for case in ("ip_200", "l2_128"):
+        exp = np.load(os.path.join(golden_dir, case + ".expected.npz"))
+        idx, q = _index(case, golden_dir, mode)
+        idx.set_option("pool_form", pool_form)
+        for kernel, waves in ((1, 1), (3, 2), (2, 4)):
+            idx.set_option("search_kernel", kernel)
+            for L in LS:
+                r = idx.SearchRoarGraphBatch(q, K, L)
+                assert idx.info("last_waves_per_query") == waves
+                assert idx.info("last_register_pool") == (1 if (L <= 64 and pool_form == 0) else 0)
+                for key in ("ids", "dists", "hops", "scanned", "cmps"):
+                    assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, kernel, L, key)
+        idx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+def test_register_pool_boundaries_random_graphs(mode, built_lib):
+    """The register-pool form at its edges: L_pq = k = 1, L_pq = 64 (every lane holds an entry), k = L_pq, first hops
+    with more than 64 survivors per merge (degrees up to 200), self loops and repeated neighbours, against the oracle."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 3000, 200, 40
+    base, q, off, nbrs = _random_case(n, d, nq, 1, seed=77, maxdeg=200)
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(5, off, nbrs)
+    idx.set_option("visited_mode", mode)
+    for kernel in (1, 3, 2):
+        idx.set_option("search_kernel", kernel)
+        for k, L in ((1, 1), (1, 2), (10, 10), (10, 33), (64, 64), (10, 64), (10, 65)):
+            o = oracle.search_batch(base, off, nbrs, 5, q, k, L, 1)
+            r = idx.SearchRoarGraphBatch(q, k, L)
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"]), (kernel, k, L)
+            assert np.array_equal(r["hops"], o["hops"]), (kernel, k, L)  # (scanned differs: repeats inside a row are dropped on upload)
+            if mode == 0:
+                assert np.array_equal(r["cmps"], o["cmps"]), (kernel, k, L)
+    idx.close()
+
+
 def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
     """BASELINE configs[0] shape through the file-based drop-in path: SIFT-like 128-d L2 set written as
     .fbin / .ibin / graph index, searched by the C++ harness (mysteryann_amd/csrc/test_search_roargraph,

@@ -150,7 +150,10 @@ int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_
  * (the pair the reference returns, :2419) and optionally scanned = sum of expanded degrees.
  * `queries`: nq rows at `qstride_floats` stride holding at least `dim` floats each; for COSINE the
  * caller normalises queries first, as the harness does (tests/test_search_roargraph.cpp:167-172).
- * Host-buffer form: H2D of queries, launch, D2H of results.  Any of cmps/hops/scanned may be NULL.
+ * Host-buffer form: the kernel reads the query rows from pinned host memory in place (the caller's block if it is
+ * pinned, see roar_host_alloc; else an internal pinned copy), results return with one asynchronous copy.  Columns
+ * [dim, padded dim) of a query row are never read from the caller (they are zero filled).  Any of
+ * cmps/hops/scanned may be NULL.
  * Safe to call from several host threads on one index (calls are serialised), like the reference's
  * re-entrant SearchRoarGraph; the device-buffer form below is one host thread per index.
  * Returns ROAR_ERR_SHORT if some query ended with fewer than k results (their tail ids are
@@ -165,6 +168,26 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
                              uint32_t k, uint32_t L_pq, uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev,
                              uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
                              void *hip_stream);
+
+/* ---- replicated index, one query block split over g devices (BASELINE configs[3]) ---------
+ * The reference has ONE query set and one timed loop over it (tests/test_search_roargraph.cpp:202-209); queries share
+ * only read-only state (src/index_bipartite.cpp:2311-2420 has no cross-query dependence), so the block shards by
+ * query with no collective.  roar_clone_to_device makes a replica of an index (base rows + projection graph + options)
+ * on another device (device-to-device copy; the same device is allowed).  roar_search_batch_multi gives replica r the
+ * queries [r * nq / g, (r + 1) * nq / g) -- one host thread + one stream per replica -- and every replica writes its
+ * own rows of the caller's arrays; arguments and errors otherwise as roar_search_batch (ROAR_ERR_SHORT if any slice
+ * had a short query, the message of the first one).  Results do not depend on g. */
+int roar_clone_to_device(roar_index *src, int device, roar_index **out);
+int roar_search_batch_multi(roar_index *const *replicas, uint32_t g, const float *queries, uint64_t nq,
+                            uint32_t qstride_floats, uint32_t k, uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps,
+                            uint32_t *hops, uint32_t *scanned);
+
+/* Pinned, device-mapped host memory for query blocks (what load_data / data_align of the facade header return):
+ * roar_search_batch reads a query block that lives in such memory in place -- no staging copy, no host-to-device
+ * copy in front of the kernel -- when its rows are strided at >= the padded dimension and the dimension needs no
+ * padding; any other host pointer works too and is packed into an internal pinned block first.  NULL on failure. */
+void *roar_host_alloc(uint64_t bytes);
+void roar_host_free(void *p);
 
 /* ---- bipartite two-hop variant (the paper's ablation baseline) -------------------
  * Graph over base nodes [0, n) and training-query nodes [n, n_total); rows of base nodes hold

@@ -8,6 +8,7 @@
 #ifndef ROARGRAPH_AMD_EFANNA2E_H
 #define ROARGRAPH_AMD_EFANNA2E_H
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -65,104 +66,142 @@ class Parameters {
 };
 
 // ---- include/efanna2e/util.h ---------------------------------------------------------------------
+// Same names, arguments, messages and padding rule as the reference's free functions; the implementation is this
+// library's: a file is sized once, read with one sized read and re-strided in memory, and float blocks that will be
+// handed to the GPU (query rows) come from pinned, device-mapped host memory (roar_host_alloc) so that
+// IndexBipartite::SearchRoarGraphBatch reads them in place.  host_free releases what these functions return.
 static const unsigned kDataAlignFactor = 8;  // DATA_ALIGN_FACTOR with AVX, util.h:38-48
 
-// util.h:106-127
+namespace detail {
+inline uint64_t round_up_dim(uint64_t d) { return (d + kDataAlignFactor - 1) / kDataAlignFactor * kDataAlignFactor; }
+
+struct FbinHeader {
+    uint32_t n = 0, d = 0;
+    uint64_t payload = 0;  // bytes after the two header words
+};
+
+// opens, reads `u32 n; u32 d`, sizes the payload; the reference prints and exits on an unopenable file (util.h:109-112)
+inline FbinHeader open_fbin(const char *filename, std::ifstream &in) {
+    in.open(filename, std::ios::binary | std::ios::ate);
+    if (!in.is_open()) {
+        std::cout << "open file error" << std::endl;
+        exit(-1);
+    }
+    FbinHeader h;
+    const uint64_t fsize = (uint64_t)in.tellg();
+    in.seekg(0, std::ios::beg);
+    in.read(reinterpret_cast<char *>(&h.n), 4);
+    in.read(reinterpret_cast<char *>(&h.d), 4);
+    h.payload = fsize >= 8 ? fsize - 8 : 0;
+    return h;
+}
+
+// pinned when a GPU runtime is there, plain 64-byte aligned memory otherwise (the loaders also run on a host-only box)
+inline std::unordered_map<void *, bool> &blocks() {
+    static std::unordered_map<void *, bool> m;
+    return m;
+}
+inline void *host_alloc(uint64_t bytes) {
+    // query-sized blocks only: pinning a multi-gigabyte base file would cost more than it can ever save
+    void *p = bytes <= (256ull << 20) ? roar_host_alloc(bytes) : nullptr;
+    const bool pinned = p != nullptr;
+    if (!p) p = aligned_alloc(64, (size_t)((bytes + 63) / 64 * 64));
+    if (!p) throw std::bad_alloc();
+    blocks()[p] = pinned;
+    return p;
+}
+inline void host_free(void *p) {
+    if (!p) return;
+    auto it = blocks().find(p);
+    const bool pinned = it != blocks().end() && it->second;
+    if (it != blocks().end()) blocks().erase(it);
+    if (pinned) roar_host_free(p);
+    else free(p);
+}
+
+// rows of `d` values -> rows of `stride` values, zero filled
+template <typename T>
+inline void restride(const T *src, uint64_t n, uint64_t d, T *dst, uint64_t stride) {
+    for (uint64_t i = 0; i < n; ++i) {
+        T *row = dst + i * stride;
+        std::copy(src + i * d, src + (i + 1) * d, row);
+        std::fill(row + d, row + stride, T(0));
+    }
+}
+}  // namespace detail
+
+inline void host_free(void *block) { detail::host_free(block); }
+
+// util.h:106-127: header of an fbin / ibin file; (payload / dim / sizeof(T)) must equal the point count
 template <typename T>
 void load_meta(const char *filename, unsigned &points_num, unsigned &dim) {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in.is_open()) {
-        std::cout << "open file error" << std::endl;
-        exit(-1);
-    }
-    in.read((char *)&points_num, 4);
-    in.read((char *)&dim, 4);
-    in.seekg(0, std::ios::end);
-    size_t fsize = (size_t)in.tellg();
-    uint32_t contained = dim ? (unsigned)((fsize - sizeof(uint32_t) * 2) / dim / sizeof(T)) : 0;
-    if (points_num != contained) {
-        std::cerr << "Data file size wrong! Get points " << contained << " but should have " << points_num << std::endl;
+    std::ifstream in;
+    const detail::FbinHeader h = detail::open_fbin(filename, in);
+    points_num = h.n;
+    dim = h.d;
+    const uint32_t contained = h.d ? (uint32_t)(h.payload / h.d / sizeof(T)) : 0u;
+    if (contained != h.n) {
+        std::cerr << "Data file size wrong! Get points " << contained << " but should have " << h.n << std::endl;
         throw std::runtime_error("Data file size wrong!");
     }
 }
 
-// util.h:84-105 (ids block + distance block: twice the payload)
+// util.h:84-105: ground truth = an id block followed by a distance block, i.e. twice the payload of load_meta
 template <typename T>
 void load_gt_meta(const char *filename, unsigned &points_num, unsigned &dim) {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in.is_open()) {
-        std::cout << "open file error" << std::endl;
-        exit(-1);
-    }
-    in.read((char *)&points_num, 4);
-    in.read((char *)&dim, 4);
-    in.seekg(0, std::ios::end);
-    size_t fsize = (size_t)in.tellg();
-    uint32_t contained = dim ? (unsigned)((fsize - sizeof(uint32_t) * 2) / dim / sizeof(T)) : 0;
-    if (points_num * 2 != contained) throw std::runtime_error("Data file size wrong!");
+    std::ifstream in;
+    const detail::FbinHeader h = detail::open_fbin(filename, in);
+    points_num = h.n;
+    dim = h.d;
+    const uint32_t contained = h.d ? (uint32_t)(h.payload / h.d / sizeof(T)) : 0u;
+    if (contained != 2u * h.n) throw std::runtime_error("Data file size wrong!");
 }
 
-// util.h:179-211: rows strided at the padded dimension, zero filled, 64-byte aligned block
+// util.h:179-211: the payload as rows strided at the dimension rounded up to 8, zero filled (pinned block)
 template <typename T>
 void load_data(const char *filename, uint32_t &points_num, uint32_t &dim, T *&data) {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in.is_open()) {
-        std::cout << "open file error" << std::endl;
-        exit(-1);
-    }
-    in.seekg(sizeof(uint32_t) * 2, std::ios::beg);
-    uint64_t pts = points_num, d = dim;
-    uint64_t new_dim = (d + kDataAlignFactor - 1) / kDataAlignFactor * kDataAlignFactor;
-    data = (T *)aligned_alloc(64, ((pts * new_dim * sizeof(T) + 63) / 64) * 64);
-    for (size_t i = 0; i < points_num; i++) {
-        in.read((char *)(data + i * new_dim), d * sizeof(T));
-        memset(data + i * new_dim + d, 0, (new_dim - d) * sizeof(T));
-    }
-    if ((size_t)in.tellg() != pts * d * sizeof(T) + sizeof(uint32_t) * 2) {
-        free(data);
-        data = nullptr;
-        throw std::runtime_error("Data file size wrong!");
-    }
+    std::ifstream in;
+    const detail::FbinHeader h = detail::open_fbin(filename, in);
+    const uint64_t n = points_num, d = dim, stride = detail::round_up_dim(d);
+    if (h.payload != n * d * sizeof(T)) throw std::runtime_error("Data file size wrong!");
+    std::vector<T> raw((size_t)(n * d));
+    in.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)(n * d * sizeof(T)));
+    if ((uint64_t)in.gcount() != n * d * sizeof(T)) throw std::runtime_error("Data file size wrong!");
+    data = static_cast<T *>(detail::host_alloc(n * stride * sizeof(T)));
+    detail::restride(raw.data(), n, d, data, stride);
 }
 
-// util.h:37-75: re-stride to the padded dimension, update dim, release the input block
+// util.h:37-75: rows of `dim` floats -> rows of the padded dimension; dim is updated, the input block released
 inline float *data_align(float *data_ori, unsigned point_num, unsigned &dim) {
-    uint64_t pts = point_num, d = dim;
-    uint64_t new_dim = (d + kDataAlignFactor - 1) / kDataAlignFactor * kDataAlignFactor;
-    float *data_new = (float *)aligned_alloc(64, ((pts * new_dim * sizeof(float) + 63) / 64) * 64);
-    for (uint64_t i = 0; i < pts; i++) {
-        memcpy(data_new + i * new_dim, data_ori + i * d, d * sizeof(float));
-        memset(data_new + i * new_dim + d, 0, (new_dim - d) * sizeof(float));
-    }
-    dim = (unsigned)new_dim;
-    free(data_ori);
-    return data_new;
+    const uint64_t n = point_num, d = dim, stride = detail::round_up_dim(d);
+    float *out = static_cast<float *>(detail::host_alloc(n * stride * sizeof(float)));
+    detail::restride(data_ori, n, d, out, stride);
+    detail::host_free(data_ori);
+    dim = (unsigned)stride;
+    return out;
 }
 
-// util.h:129-155
+// util.h:129-155: ids block then distances block, both points_num x dim (new[] blocks, as in the reference)
 template <typename T, typename T2>
 void load_gt_data_with_dist(const char *filename, uint32_t &points_num, uint32_t &dim, T *&data, T2 *&res_dists) {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in.is_open()) {
-        std::cout << "open file error" << std::endl;
-        exit(-1);
-    }
-    in.seekg(sizeof(uint32_t) * 2, std::ios::beg);
-    data = new T[(size_t)points_num * dim];
-    res_dists = new T2[(size_t)points_num * dim];
-    in.read((char *)data, (size_t)points_num * dim * sizeof(T));
-    in.read((char *)res_dists, (size_t)points_num * dim * sizeof(T2));
-    if ((size_t)in.tellg() != (size_t)points_num * dim * sizeof(T) * 2 + sizeof(uint32_t) * 2)
-        throw std::runtime_error("Data file size wrong!");
+    std::ifstream in;
+    const detail::FbinHeader h = detail::open_fbin(filename, in);
+    const uint64_t cells = (uint64_t)points_num * dim;
+    if (h.payload != cells * (sizeof(T) + sizeof(T2))) throw std::runtime_error("Data file size wrong!");
+    data = new T[(size_t)cells];
+    res_dists = new T2[(size_t)cells];
+    in.read(reinterpret_cast<char *>(data), (std::streamsize)(cells * sizeof(T)));
+    in.read(reinterpret_cast<char *>(res_dists), (std::streamsize)(cells * sizeof(T2)));
+    if (!in) throw std::runtime_error("Data file size wrong!");
 }
 
-// util.h:214-225
+// util.h:214-225: x / |x|, the norm summed sequentially in float
 template <typename T>
 inline void normalize(T *arr, const size_t dim) {
-    float sum = 0.0f;
-    for (size_t i = 0; i < dim; i++) sum += arr[i] * arr[i];
-    sum = std::sqrt(sum);
-    for (size_t i = 0; i < dim; i++) arr[i] = (T)(arr[i] / sum);
+    float norm2 = 0.0f;
+    for (const T *p = arr; p != arr + dim; ++p) norm2 += (float)(*p) * (float)(*p);
+    const float norm = std::sqrt(norm2);
+    for (T *p = arr; p != arr + dim; ++p) *p = (T)(*p / norm);
 }
 
 // ---- include/index_bipartite.h (search path only) -------------------------------------------------
@@ -179,6 +218,7 @@ class IndexBipartite {
         if (m == COSINE) need_normalize = true;
     }
     ~IndexBipartite() {
+        for (roar_index *r : replicas_) roar_destroy(r);
         if (h_) roar_destroy(h_);
     }
     IndexBipartite(const IndexBipartite &) = delete;
@@ -250,11 +290,31 @@ class IndexBipartite {
 
     // New: the whole query block in one launch (what `#pragma omp parallel for` over SearchRoarGraph
     // does in tests/test_search_roargraph.cpp:203-209).  queries: nq rows, `dimension` floats apart.
+    // With replicas (Replicate) the block is split by query over the devices: replica r takes queries
+    // [r * nq / g, (r + 1) * nq / g) and writes those rows of ids / dists / cmps / hops (no collective).
     void SearchRoarGraphBatch(const float *queries, size_t nq, size_t k, uint32_t L_pq, unsigned *ids, float *dists,
                               uint32_t *cmps, uint32_t *hops) {
-        check(roar_search_batch(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, L_pq, ids, dists, cmps, hops,
-                                nullptr));
+        if (replicas_.empty()) {
+            check(roar_search_batch(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, L_pq, ids, dists, cmps, hops,
+                                    nullptr));
+            return;
+        }
+        std::vector<roar_index *> all(1, handle());
+        all.insert(all.end(), replicas_.begin(), replicas_.end());
+        check(roar_search_batch_multi(all.data(), (uint32_t)all.size(), queries, nq, (uint32_t)dimension_, (uint32_t)k, L_pq,
+                                      ids, dists, cmps, hops, nullptr));
     }
+    // New: the index replicated on further devices (BASELINE configs[3]: index replicated, queries sharded).  Call
+    // after the base rows and the projection graph are loaded; options set before are copied, later SetOption calls
+    // reach every replica.
+    void Replicate(const std::vector<int> &devices) {
+        for (int d : devices) {
+            roar_index *r = nullptr;
+            check(roar_clone_to_device(handle(), d, &r));
+            replicas_.push_back(r);
+        }
+    }
+    size_t NumReplicas() const { return replicas_.size() + 1; }
 
     // ---- bipartite two-hop variant (the ablation baseline) ---------------------------------------
     // index_bipartite.h:35-36, src/index_bipartite.cpp:42-141 -> qbaseNNbipartite :235-280
@@ -296,7 +356,10 @@ class IndexBipartite {
     void ExactKnn(const float *queries, size_t nq, size_t k, unsigned *ids, float *dists) {
         check(roar_exact_knn(handle(), queries, nq, (uint32_t)dimension_, (uint32_t)k, ids, dists));
     }
-    void SetOption(const char *key, int64_t v) { check(roar_set_option(handle(), key, v)); }
+    void SetOption(const char *key, int64_t v) {
+        check(roar_set_option(handle(), key, v));
+        for (roar_index *r : replicas_) check(roar_set_option(r, key, v));
+    }
     int64_t Info(const char *key) {
         int64_t v = 0;
         check(roar_get_info(handle(), key, &v));
@@ -324,6 +387,7 @@ class IndexBipartite {
     Metric metric_;
     int device_;
     roar_index *h_ = nullptr;
+    std::vector<roar_index *> replicas_;
     std::vector<uint32_t> learn_base_knn_;  // index_bipartite.h:153
     uint32_t knn_n_ = 0, knn_k_ = 0;
 };

@@ -24,7 +24,8 @@ SYMBOLS = [
     "roar_merge_topk_device", "roar_set_option", "roar_get_info", "roar_init_visited_pool",
     "roar_load_bipartite_file", "roar_save_bipartite_file", "roar_set_bipartite_csr", "roar_get_bipartite_csr",
     "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
-    "roar_search_bipartite_batch_device", "roar_last_profile",
+    "roar_search_bipartite_batch_device", "roar_last_profile", "roar_clone_to_device", "roar_search_batch_multi",
+    "roar_host_alloc", "roar_host_free",
 ]
 
 
@@ -103,6 +104,13 @@ def lib():
     l.roar_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     l.roar_init_visited_pool.argtypes = [vp, C.c_uint32]
     l.roar_last_profile.argtypes = [vp, u64p, C.c_uint64]
+    l.roar_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    l.roar_search_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp,
+                                          u32p, u32p, u32p]
+    l.roar_host_alloc.argtypes = [C.c_uint64]
+    l.roar_host_alloc.restype = vp
+    l.roar_host_free.argtypes = [vp]
+    l.roar_host_free.restype = None
     l.roar_load_bipartite_file.argtypes = [vp, C.c_char_p]
     l.roar_save_bipartite_file.argtypes = [vp, C.c_char_p]
     l.roar_set_bipartite_csr.argtypes = [vp, C.c_uint64, u64p, u32p]
@@ -114,7 +122,7 @@ def lib():
     l.roar_search_bipartite_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     for s in SYMBOLS:
-        if s not in ("roar_destroy", "roar_last_error"):
+        if s not in ("roar_destroy", "roar_last_error", "roar_host_alloc", "roar_host_free"):
             getattr(l, s).restype = C.c_int
     _lib = l
     return l

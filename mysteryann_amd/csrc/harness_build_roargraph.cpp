@@ -86,8 +86,8 @@ int main(int argc, char **argv) {
             std::cout << "Save index to " << bipartite_index_save_file << std::endl;
             std::cout << "Bipartite nodes: " << index_bipartite.Info("bipartite_nodes")
                       << " edges: " << index_bipartite.Info("bipartite_edges") << std::endl;
-            free(data_bp);
-            free(data_sq);
+            efanna2e::host_free(data_bp);
+            efanna2e::host_free(data_sq);
             return 0;
         }
         index_bipartite.BuildRoarGraph(sq_num, data_sq, base_num, data_bp, parameters);
@@ -97,8 +97,8 @@ int main(int argc, char **argv) {
         std::cout << "Save index to " << projection_index_save_file << std::endl;
         std::cout << "Projection degree avg: " << (double)index_bipartite.Info("nedges") / (double)base_num << std::endl;
         std::cout << "Projection degree max: " << index_bipartite.Info("max_degree") << std::endl;
-        free(data_bp);
-        free(data_sq);
+        efanna2e::host_free(data_bp);
+        efanna2e::host_free(data_sq);
     } catch (const std::exception &ex) {
         std::cerr << ex.what() << '\n';
         return -1;

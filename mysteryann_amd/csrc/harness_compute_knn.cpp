@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
         out.write((char *)ids.data(), (std::streamsize)ids.size() * 4);
         if (with_dists) out.write((char *)dists.data(), (std::streamsize)dists.size() * 4);
         std::cout << "wrote " << out_file << ": " << nq << " x " << K << (with_dists ? " ids + distances" : " ids") << std::endl;
-        free(q);
+        efanna2e::host_free(q);
     } catch (const std::exception &ex) {
         std::cerr << ex.what() << '\n';
         return -1;

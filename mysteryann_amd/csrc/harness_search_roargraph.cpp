@@ -70,7 +70,10 @@ static void usage() {
                  "  --rderr                      also print / save the relative distance error (7th CSV column)\n"
                  "  --bipartite_index_save_path <index>  search the bipartite graph instead (SearchBipartiteGraph)\n"
                  "  --entry_seed <n>             seed of the bipartite entry-point draws\n"
-                 "  --device <ordinal>\n";
+                 "  --device <ordinal>\n"
+                 "  --gpus <g>                   index replicated on devices device .. device + g - 1, the query block split by\n"
+                 "                               query over them (no collective); 0 = every visible device; default 1\n"
+                 "  --devices <d0,d1,...>        explicit replica placement (a device may repeat); overrides --gpus\n";
 }
 
 int main(int argc, char **argv) {
@@ -80,7 +83,8 @@ int main(int argc, char **argv) {
     bool want_rderr = false;
     std::vector<uint32_t> L_vec;
     uint32_t num_threads = omp_get_num_procs(), k = 1;
-    int device = 0;
+    int device = 0, gpus = 1;
+    std::vector<int> device_list;
     bool per_query = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -106,6 +110,17 @@ int main(int argc, char **argv) {
         else if (a == "--k") k = (uint32_t)std::stoul(next());
         else if (a == "-T" || a == "--num_threads") num_threads = (uint32_t)std::stoul(next());
         else if (a == "--device") device = std::stoi(next());
+        else if (a == "--gpus") gpus = std::stoi(next());
+        else if (a == "--devices") {
+            std::string v = next();
+            for (size_t p0 = 0; p0 <= v.size();) {
+                size_t p1 = v.find(',', p0);
+                if (p1 == std::string::npos) p1 = v.size();
+                device_list.push_back(std::stoi(v.substr(p0, p1 - p0)));
+                p0 = p1 + 1;
+            }
+            if (!device_list.empty()) device = device_list[0];
+        }
         else if (a == "--visited") visited = next();
         else if (a == "--per_query") per_query = true;
         else if (a == "--rderr") want_rderr = true;
@@ -184,6 +199,25 @@ int main(int argc, char **argv) {
             std::cout << "Normalizing query data" << std::endl;
             for (uint32_t i = 0; i < q_pts; i++) efanna2e::normalize<float>(aligned_query_data + (size_t)i * q_dim, q_dim);
         }
+        if (!device_list.empty() && !bipartite) {
+            index.Replicate(std::vector<int>(device_list.begin() + 1, device_list.end()));
+            std::cout << "Index replicated on " << index.NumReplicas() << " devices, queries sharded" << std::endl;
+        } else if (gpus != 1 && !bipartite) {  // replicate after load: one host thread + stream per device inside the library
+            int have = 0;
+            if (gpus <= 0) {
+                while (true) {  // count devices by asking for an index on each
+                    roar_index *probe = nullptr;
+                    if (roar_create(&probe, 8, ROAR_METRIC_L2, have) != ROAR_OK) break;
+                    roar_destroy(probe);
+                    ++have;
+                }
+                gpus = std::max(1, have - device);
+            }
+            std::vector<int> extra;
+            for (int g = 1; g < gpus; ++g) extra.push_back(device + g);
+            index.Replicate(extra);
+            std::cout << "Index replicated on " << index.NumReplicas() << " devices, queries sharded" << std::endl;
+        }
         index.SetOption("visited_mode", visited == "exact" ? ROAR_VISITED_EXACT
                                         : visited == "lds" ? ROAR_VISITED_LDS : ROAR_VISITED_AUTO);
         if (visited == "exact") index.InitVisitedListPool(num_threads);
@@ -259,7 +293,7 @@ int main(int argc, char **argv) {
                 evaluation_out << std::endl;
             }
         }
-        free(aligned_query_data);
+        efanna2e::host_free(aligned_query_data);
         delete[] gt_ids;
         delete[] gt_dists;
     } catch (const std::exception &ex) {

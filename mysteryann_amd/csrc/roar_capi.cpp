@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/roargraph_amd.h"
@@ -122,10 +123,14 @@ struct roar_index {
     uint64_t tag_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
-    // host-API staging
-    float *q_dev = nullptr;
+    // host-API staging: queries are packed into pinned host memory that the kernel reads in place (no H2D step),
+    // results come back through a pinned block with one asynchronous copy; everything on the index's own stream
+    hipStream_t stream = nullptr;
+    float *q_pin = nullptr;      // pinned + mapped
+    float *q_pin_dev = nullptr;  // its device address
     uint64_t q_cap = 0;
     uint32_t *out_dev = nullptr;
+    uint32_t *out_pin = nullptr;
     uint64_t out_cap = 0;
     // SearchRoarGraph is re-entrant in the reference (called from num_threads OpenMP threads,
     // tests/test_search_roargraph.cpp:203); the host-buffer entry points share staging buffers, the
@@ -487,66 +492,79 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     return ROAR_OK;
 }
 
-// stage queries padded to dim_pad (data_align of the query block, tests/test_search_roargraph.cpp:131)
-// and size the result block [ids | dists | cmps | hops | scanned | short]
-int stage_queries(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k) {
-    const uint64_t qfloats = nq * idx->dim_pad;
-    if (idx->q_cap < qfloats) {
-        if (idx->q_dev) (void)hipFree(idx->q_dev);
-        idx->q_dev = nullptr;
-        HIP_TRY(hipMalloc((void **)&idx->q_dev, (size_t)qfloats * sizeof(float)));
-        idx->q_cap = qfloats;
-    }
+// Host-buffer queries -> something the kernel can read.  Rows are padded to dim_pad with zeros (data_align of the
+// query block, tests/test_search_roargraph.cpp:131).  Two ways, neither with a host-to-device copy in front of the
+// kernel: (1) the caller's block is already pinned (roar_host_alloc, hipHostMalloc, hipHostRegister), strided at
+// >= dim_pad floats with nothing to zero -> the kernel reads it in place over PCIe (each query is read once, 4 * dim
+// bytes, at its own start: 8 MB per 10 000 queries, hidden under the search); (2) otherwise the rows are packed into
+// the index's pinned staging block by a few host threads and read from there.  *qdev / *qstride: what to launch with.
+int stage_queries(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, const float **qdev,
+                  uint32_t *qstride) {
     const uint64_t owords = nq * (2ull * k + 3) + 1;
     if (idx->out_cap < owords) {
         if (idx->out_dev) (void)hipFree(idx->out_dev);
-        idx->out_dev = nullptr;
+        if (idx->out_pin) (void)hipHostFree(idx->out_pin);
+        idx->out_dev = idx->out_pin = nullptr;
+        idx->out_cap = 0;
         HIP_TRY(hipMalloc((void **)&idx->out_dev, (size_t)owords * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void **)&idx->out_pin, (size_t)owords * sizeof(uint32_t), hipHostMallocDefault));
         idx->out_cap = owords;
     }
-    if (qstride_floats == idx->dim_pad) {
-        HIP_TRY(hipMemcpy(idx->q_dev, queries, (size_t)qfloats * sizeof(float), hipMemcpyHostToDevice));
-    } else {
-        std::vector<float> buf((size_t)qfloats, 0.0f);
-        for (uint64_t i = 0; i < nq; ++i)
-            memcpy(buf.data() + i * idx->dim_pad, queries + i * qstride_floats,
-                   std::min<uint32_t>(qstride_floats, idx->dim_pad) * sizeof(float));
-        if (qstride_floats > idx->dim)  // anything past dim is padding and must read as zero
-            for (uint64_t i = 0; i < nq; ++i)
-                memset(buf.data() + i * idx->dim_pad + idx->dim, 0, (idx->dim_pad - idx->dim) * sizeof(float));
-        HIP_TRY(hipMemcpy(idx->q_dev, buf.data(), (size_t)qfloats * sizeof(float), hipMemcpyHostToDevice));
+    if (idx->dim == idx->dim_pad && qstride_floats >= idx->dim_pad && (qstride_floats & 3) == 0) {
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof attr);
+        if (hipPointerGetAttributes(&attr, queries) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+            *qdev = static_cast<const float *>(attr.devicePointer);
+            *qstride = qstride_floats;
+            return ROAR_OK;
+        }
+        (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
     }
+    const uint64_t qfloats = nq * idx->dim_pad;
+    if (idx->q_cap < qfloats) {
+        if (idx->q_pin) (void)hipHostFree(idx->q_pin);
+        idx->q_pin = idx->q_pin_dev = nullptr;
+        idx->q_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&idx->q_pin, (size_t)qfloats * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&idx->q_pin_dev, idx->q_pin, 0));
+        idx->q_cap = qfloats;
+    }
+    const uint32_t dp = idx->dim_pad, d = idx->dim;
+    auto pack = [&](uint64_t r0, uint64_t r1) {
+        for (uint64_t i = r0; i < r1; ++i) {
+            float *dst = idx->q_pin + i * dp;
+            memcpy(dst, queries + i * qstride_floats, d * sizeof(float));
+            if (dp > d) memset(dst + d, 0, (dp - d) * sizeof(float));  // anything past dim is padding and must read as zero
+        }
+    };
+    const unsigned nthreads = qfloats >= (1u << 20) ? 4u : 1u;
+    if (nthreads == 1) {
+        pack(0, nq);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(pack, nq * t / nthreads, nq * (t + 1) / nthreads);
+        pack(0, nq / nthreads);
+        for (auto &x : th) x.join();
+    }
+    *qdev = idx->q_pin_dev;
+    *qstride = dp;
     return ROAR_OK;
 }
 
+// results: one asynchronous copy of the block [ids | dists | cmps | hops | scanned | short] into pinned memory,
+// then plain copies into the caller's arrays
 int fetch_results(roar_index *idx, uint64_t nq, uint32_t k, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
                   uint32_t *scanned) {
-    uint32_t *d_ids = idx->out_dev;
-    float *d_dists = reinterpret_cast<float *>(d_ids + nq * k);
-    uint32_t *d_cmps = d_ids + 2 * nq * k;
-    uint32_t *d_hops = d_cmps + nq;
-    uint32_t *d_scan = d_hops + nq;
-    uint32_t *d_short = d_scan + nq;
-    // small batches (the combined one-query calls): one copy of the whole result block instead of six
-    uint32_t nshort = 0;
     const uint64_t words = nq * (2ull * k + 3) + 1;
-    if (words <= (1u << 16)) {
-        std::vector<uint32_t> blk((size_t)words);
-        HIP_TRY(hipMemcpy(blk.data(), d_ids, (size_t)words * 4, hipMemcpyDeviceToHost));
-        memcpy(ids, blk.data(), (size_t)nq * k * 4);
-        memcpy(dists, blk.data() + nq * k, (size_t)nq * k * 4);
-        if (cmps) memcpy(cmps, blk.data() + 2 * nq * k, (size_t)nq * 4);
-        if (hops) memcpy(hops, blk.data() + 2 * nq * k + nq, (size_t)nq * 4);
-        if (scanned) memcpy(scanned, blk.data() + 2 * nq * k + 2 * nq, (size_t)nq * 4);
-        nshort = blk[(size_t)words - 1];
-    } else {
-        HIP_TRY(hipMemcpy(ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(dists, d_dists, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-        if (cmps) HIP_TRY(hipMemcpy(cmps, d_cmps, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        if (hops) HIP_TRY(hipMemcpy(hops, d_hops, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        if (scanned) HIP_TRY(hipMemcpy(scanned, d_scan, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&nshort, d_short, 4, hipMemcpyDeviceToHost));
-    }
+    HIP_TRY(hipMemcpyAsync(idx->out_pin, idx->out_dev, (size_t)words * 4, hipMemcpyDeviceToHost, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    const uint32_t *blk = idx->out_pin;
+    memcpy(ids, blk, (size_t)nq * k * 4);
+    memcpy(dists, blk + nq * k, (size_t)nq * k * 4);
+    if (cmps) memcpy(cmps, blk + 2 * nq * k, (size_t)nq * 4);
+    if (hops) memcpy(hops, blk + 2 * nq * k + nq, (size_t)nq * 4);
+    if (scanned) memcpy(scanned, blk + 2 * nq * k + 2 * nq, (size_t)nq * 4);
+    const uint32_t nshort = blk[(size_t)words - 1];
     if (nshort) {
         // message of the first short query, as the reference would have thrown it (:2408-2412)
         for (uint64_t i = 0; i < nq; ++i) {
@@ -577,20 +595,32 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
         return fail(ROAR_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     if (device < 0 || device >= count) return fail(ROAR_ERR_ARG, "device %d out of range (%d devices)", device, count);
-    roar_index *idx = new roar_index();
+    roar_index *idx = new (std::nothrow) roar_index();
+    if (!idx) return fail(ROAR_ERR_DEVICE, "out of host memory");
     idx->device = device;
     idx->dim = dim;
     idx->dim_pad = round_up(dim, 8);  // DATA_ALIGN_FACTOR, util.h:38-48
     idx->metric = metric;
     idx->ip = metric != ROAR_METRIC_L2;          // src/index.cpp:11-24
     idx->need_normalize = metric == ROAR_METRIC_COSINE;  // src/index_bipartite.cpp:35-37
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    idx->n_cus = prop.multiProcessorCount;
-    HIP_TRY(hipMalloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
-    HIP_TRY(hipEventCreate(&idx->ev0));
-    HIP_TRY(hipEventCreate(&idx->ev1));
+    auto init = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        idx->n_cus = prop.multiProcessorCount;
+        HIP_TRY(hipMalloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&idx->ev0));
+        HIP_TRY(hipEventCreate(&idx->ev1));
+        return ROAR_OK;
+    };
+    const int e2 = init();
+    if (e2) {
+        const std::string keep = g_err;
+        roar_destroy(idx);
+        g_err = keep;
+        return e2;
+    }
     *out = idx;
     return ROAR_OK;
 }
@@ -604,8 +634,10 @@ void roar_destroy(roar_index *idx) {
     free_tags(idx);
     if (idx->init_dev) (void)hipFree(idx->init_dev);
     if (idx->counters) (void)hipFree(idx->counters);
-    if (idx->q_dev) (void)hipFree(idx->q_dev);
+    if (idx->q_pin) (void)hipHostFree(idx->q_pin);
     if (idx->out_dev) (void)hipFree(idx->out_dev);
+    if (idx->out_pin) (void)hipHostFree(idx->out_pin);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
     if (idx->prof_dev) (void)hipFree(idx->prof_dev);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -858,21 +890,29 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
     uint32_t *res_ids = nullptr, *indeg = nullptr, *scratch = nullptr, *base_deg = nullptr;
     float *res_d = nullptr, *sums = nullptr;
-    HIP_TRY(hipMalloc((void **)&res_ids, (size_t)cap * K * 4));
-    HIP_TRY(hipMalloc((void **)&res_d, (size_t)cap * K * 4));
-    HIP_TRY(hipMalloc((void **)&indeg, (size_t)n * 4));
-    HIP_TRY(hipMemset(indeg, 0, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&base_deg, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&scratch, 16));
     const int saved_mode = idx->visited_mode;
-    auto cleanup = [&]() {
+    auto cleanup = [&]() {  // every exit below goes through here: workspaces freed, search state restored
         (void)hipFree(res_ids); (void)hipFree(res_d); (void)hipFree(indeg); (void)hipFree(sums); (void)hipFree(scratch);
         (void)hipFree(base_deg);
         idx->visited_mode = saved_mode;
         idx->building = false;
         idx->ip = idx->metric != ROAR_METRIC_L2;
     };
+#define HIP_TRYC(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            cleanup();                                                                              \
+            return fail(ROAR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));                   \
+        }                                                                                           \
+    } while (0)
+    HIP_TRYC(hipMalloc((void **)&res_ids, (size_t)cap * K * 4));
+    HIP_TRYC(hipMalloc((void **)&res_d, (size_t)cap * K * 4));
+    HIP_TRYC(hipMalloc((void **)&indeg, (size_t)n * 4));
+    HIP_TRYC(hipMemset(indeg, 0, (size_t)n * 4));
+    HIP_TRYC(hipMalloc((void **)&base_deg, (size_t)n * 4));
+    HIP_TRYC(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
+    HIP_TRYC(hipMalloc((void **)&scratch, 16));
 #define BK_TRY(call)                                                                        \
     do {                                                                                    \
         int rc_ = (call);                                                                   \
@@ -884,7 +924,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // entry point: node nearest the centroid (CalculateProjectionep, src/index_bipartite.cpp:2004-2041)
     BK_TRY(roar_bk_entry_point(idx->base, idx->ld, idx->dim_pad, n, sums, (unsigned long long *)scratch, nullptr));
     unsigned long long best = 0;
-    HIP_TRY(hipMemcpy(&best, scratch, 8, hipMemcpyDeviceToHost));
+    HIP_TRYC(hipMemcpy(&best, scratch, 8, hipMemcpyDeviceToHost));
     idx->ep = (uint32_t)(best & 0xFFFFFFFFu);
     const uint32_t seed = (uint32_t)std::min<uint64_t>(n, 1024);
     if (!bp->no_skeleton) BK_TRY(roar_bk_seed(idx->adj, S, seed, idx->ep, std::min<uint32_t>(M, seed - 1), nullptr));
@@ -997,16 +1037,17 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     for (uint32_t r = 0; r < 8; ++r) {
         BK_TRY(roar_bk_rescue(idx->adj, S, max_degree, n, idx->ep, r, indeg, scratch, nullptr));
         uint32_t orphans = 0;
-        HIP_TRY(hipMemcpy(&orphans, scratch, 4, hipMemcpyDeviceToHost));
+        HIP_TRYC(hipMemcpy(&orphans, scratch, 4, hipMemcpyDeviceToHost));
         if (orphans == 0) break;
     }
     BK_TRY(roar_bk_dedupe(idx->adj, S, max_degree, n, nullptr));
     BK_TRY(roar_bk_degree_stats(idx->adj, S, n, (unsigned long long *)scratch, scratch + 2, nullptr));
     unsigned long long st[2] = {0, 0};
-    HIP_TRY(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));
+    HIP_TRYC(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));
     idx->nedges = st[0];
     idx->max_deg = (uint32_t)(st[1] & 0xFFFFFFFFu);
 #undef BK_TRY
+#undef HIP_TRYC
     cleanup();
     return ROAR_OK;
 }
@@ -1100,19 +1141,30 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
 
 // The reference's harness calls SearchRoarGraph once per query from num_threads OpenMP threads
 // (tests/test_search_roargraph.cpp:203-209).  One-query launches would leave the GPU idle, so concurrent
-// one-query calls are combined: the first caller becomes the leader, gathers every request queued with the same
-// (k, L_pq) -- those that arrived while the previous launch was in flight -- runs them as one batch and hands
-// each caller its own rows; callers that find a leader wait for their result.  Results are those of the
-// batch path, i.e. of the reference, query by query.
+// one-query calls are combined: a caller that finds no leader becomes the leader, takes every request queued with
+// the same (k, L_pq) as the oldest one -- those that arrived while the previous launch was in flight -- runs them as
+// one batch and hands each caller its own rows.  A leader serves exactly one batch: when its own request is done it
+// returns, and a caller still waiting takes over (so no caller's latency grows with the load of the others).  Nothing
+// thrown inside a leader's turn escapes the C ABI or leaves the queue without a leader: the batch is failed instead.
+// Results are those of the batch path, i.e. of the reference, query by query.
 int search_one(roar_index *idx, roar_index::OneQuery &req) {
     std::unique_lock<std::mutex> lk(idx->cq_mu);
-    idx->cq.push_back(&req);
-    if (idx->cq_leader) {
-        idx->cq_cv.wait(lk, [&] { return req.done; });
-    } else {
+    try {
+        idx->cq.push_back(&req);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory");
+    }
+    while (!req.done) {
+        if (idx->cq_leader) {
+            idx->cq_cv.wait(lk, [&] { return req.done || !idx->cq_leader; });
+            continue;
+        }
         idx->cq_leader = true;
-        while (!idx->cq.empty()) {
-            std::vector<roar_index::OneQuery *> batch, rest;
+        std::vector<roar_index::OneQuery *> batch;
+        int rc = ROAR_OK;
+        std::string err;
+        try {
+            std::vector<roar_index::OneQuery *> rest;
             const roar_index::OneQuery *head = idx->cq.front();
             for (roar_index::OneQuery *r : idx->cq)
                 ((r->k == head->k && r->L == head->L && batch.size() < 4096) ? batch : rest).push_back(r);
@@ -1125,13 +1177,12 @@ int search_one(roar_index *idx, roar_index::OneQuery &req) {
                 memcpy(&qbuf[i * dp], batch[i]->q, std::min(batch[i]->qstride, idx->dim) * sizeof(float));
             std::vector<uint32_t> r_ids((size_t)m * k), r_cmps(m), r_hops(m), r_scan(m);
             std::vector<float> r_d((size_t)m * k);
-            int rc = search_host(idx, qbuf.data(), m, dp, k, head->L, r_ids.data(), r_d.data(), r_cmps.data(), r_hops.data(),
-                                 r_scan.data());
-            const std::string err = g_err;
+            rc = search_host(idx, qbuf.data(), m, dp, k, head->L, r_ids.data(), r_d.data(), r_cmps.data(), r_hops.data(),
+                             r_scan.data());
+            err = g_err;
             for (uint64_t i = 0; i < m; ++i) {
                 roar_index::OneQuery *r = batch[i];
                 r->rc = rc;
-                r->err = err;
                 if (rc == ROAR_OK || rc == ROAR_ERR_SHORT) {
                     memcpy(r->ids, &r_ids[i * k], k * sizeof(uint32_t));
                     memcpy(r->dists, &r_d[i * k], k * sizeof(float));
@@ -1147,14 +1198,24 @@ int search_one(roar_index *idx, roar_index::OneQuery &req) {
                         r->rc = ROAR_ERR_SHORT;
                         r->err = msg;
                     }
+                } else {
+                    r->err = err;
                 }
             }
-            lk.lock();
-            idx->last_combined = (int64_t)m;
-            for (roar_index::OneQuery *r : batch) r->done = true;
-            idx->cq_cv.notify_all();
+        } catch (...) {  // std::bad_alloc in the staging vectors: fail this batch, keep the queue alive
+            for (roar_index::OneQuery *r : batch) {
+                r->rc = ROAR_ERR_DEVICE;
+                try {
+                    r->err = "out of host memory while combining one-query calls";
+                } catch (...) {
+                }
+            }
         }
+        if (!lk.owns_lock()) lk.lock();
+        idx->last_combined = (int64_t)batch.size();
+        for (roar_index::OneQuery *r : batch) r->done = true;
         idx->cq_leader = false;
+        idx->cq_cv.notify_all();
     }
     if (req.rc != ROAR_OK) g_err = req.err;
     return req.rc;
@@ -1182,20 +1243,142 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
     std::lock_guard<std::mutex> guard(idx->mu);
     int e = use_device(idx);
     if (e) return e;
-    if ((e = stage_queries(idx, queries, nq, qstride_floats, k))) return e;
+    const float *qdev = nullptr;
+    uint32_t qs = 0;
+    if ((e = stage_queries(idx, queries, nq, qstride_floats, k, &qdev, &qs))) return e;
     uint32_t *d_ids = idx->out_dev;
     float *d_dists = reinterpret_cast<float *>(d_ids + nq * k);
     uint32_t *d_cmps = d_ids + 2 * nq * k;
     uint32_t *d_hops = d_cmps + nq;
     uint32_t *d_scan = d_hops + nq;
     uint32_t *d_short = d_scan + nq;
-    e = roar_search_batch_device(idx, idx->q_dev, nq, idx->dim_pad, k, L_pq, d_ids, d_dists, d_cmps, d_hops, d_scan,
-                                 d_short, nullptr);
+    e = roar_search_batch_device(idx, qdev, nq, qs, k, L_pq, d_ids, d_dists, d_cmps, d_hops, d_scan, d_short, idx->stream);
     if (e) return e;
-    HIP_TRY(hipDeviceSynchronize());
     return fetch_results(idx, nq, k, ids, dists, cmps, hops, scanned);
 }
 }  // namespace
+
+// ---- replicated index, one query block split over g devices (BASELINE configs[3]) --------------------
+
+int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
+    if (!src || !out) return fail(ROAR_ERR_ARG, "bad arguments");
+    *out = nullptr;
+    if (!src->base || src->n == 0) return fail(ROAR_ERR_ARG, "clone before base vectors were loaded");
+    roar_index *dst = nullptr;
+    int e = roar_create(&dst, src->dim, src->metric, device);
+    if (e) return e;
+    auto bail = [&](int code) {
+        const std::string keep = g_err;
+        roar_destroy(dst);
+        g_err = keep;
+        return code;
+    };
+    std::lock_guard<std::mutex> guard(src->mu);
+    dst->visited_mode = src->visited_mode;
+    dst->waves_per_cu = src->waves_per_cu;
+    dst->vis_entries = src->vis_entries;
+    dst->max_grid = src->max_grid;
+    dst->search_kernel = src->search_kernel;
+    dst->pool_form = src->pool_form;
+    dst->combine = src->combine;
+    if ((e = alloc_base(dst, src->n))) return bail(e);
+    // rows are re-strided to the padded dimension if the source adopted a wider block
+    hipError_t he = hipSuccess;
+    if (src->ld == dst->ld) {
+        he = hipMemcpyPeer(dst->base, dst->device, src->base, src->device, (size_t)src->n * src->ld * sizeof(float));
+    } else {
+        he = hipMemcpy2D(dst->base, (size_t)dst->ld * 4, src->base, (size_t)src->ld * 4, (size_t)dst->ld * 4, (size_t)src->n,
+                         hipMemcpyDefault);
+    }
+    if (he != hipSuccess) return bail(fail(ROAR_ERR_DEVICE, "copy of the base rows to device %d failed: %s", device, hipGetErrorString(he)));
+    if (src->adj) {
+        const size_t words = (size_t)src->gn * src->adj_stride + ADJ_SLACK_WORDS;
+        if (hipMalloc((void **)&dst->adj, words * sizeof(uint32_t)) != hipSuccess)
+            return bail(fail(ROAR_ERR_DEVICE, "out of device memory for the graph replica"));
+        he = hipMemcpyPeer(dst->adj, dst->device, src->adj, src->device, words * sizeof(uint32_t));
+        if (he != hipSuccess) return bail(fail(ROAR_ERR_DEVICE, "copy of the graph to device %d failed: %s", device, hipGetErrorString(he)));
+        dst->adj_stride = src->adj_stride;
+        dst->ep = src->ep;
+        dst->max_deg = src->max_deg;
+        dst->gn = src->gn;
+        dst->nedges = src->nedges;  // the host CSR copy is rebuilt from the device rows if it is ever asked for
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = dst;
+    return ROAR_OK;
+}
+
+int roar_search_batch_multi(roar_index *const *replicas, uint32_t g, const float *queries, uint64_t nq, uint32_t qstride_floats,
+                            uint32_t k, uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
+                            uint32_t *scanned) {
+    if (!replicas || g == 0 || g > 64) return fail(ROAR_ERR_ARG, "between 1 and 64 replicas");
+    if (!ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
+    for (uint32_t r = 0; r < g; ++r) {
+        if (!replicas[r]) return fail(ROAR_ERR_ARG, "replica %u is null", r);
+        if (replicas[r]->dim != replicas[0]->dim || replicas[r]->n != replicas[0]->n || replicas[r]->gn != replicas[0]->gn ||
+            replicas[r]->metric != replicas[0]->metric)
+            return fail(ROAR_ERR_ARG, "replica %u does not hold the same index as replica 0", r);
+    }
+    if (nq == 0) return ROAR_OK;
+    if (qstride_floats < replicas[0]->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    // replica r takes queries [r * nq / g, (r + 1) * nq / g) and writes the same rows of the caller's arrays
+    std::vector<int> rc(g, ROAR_OK);
+    std::vector<std::string> msg(g);
+    auto work = [&](uint32_t r) {
+        const uint64_t lo = nq * r / g, hi = nq * (r + 1) / g;
+        if (hi == lo) return;
+        try {
+            rc[r] = search_host(replicas[r], queries + lo * qstride_floats, hi - lo, qstride_floats, k, L_pq, ids + lo * k,
+                                dists + lo * k, cmps ? cmps + lo : nullptr, hops ? hops + lo : nullptr,
+                                scanned ? scanned + lo : nullptr);
+            if (rc[r] != ROAR_OK) msg[r] = g_err;
+        } catch (...) {
+            rc[r] = ROAR_ERR_DEVICE;
+            msg[r] = "out of host memory in a replica's search";
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        try {
+            for (uint32_t r = 1; r < g; ++r) th.emplace_back(work, r);
+        } catch (...) {
+            for (auto &x : th) x.join();
+            return fail(ROAR_ERR_DEVICE, "cannot start the per-device host threads");
+        }
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    int first_short = -1;
+    for (uint32_t r = 0; r < g; ++r) {
+        if (rc[r] == ROAR_ERR_SHORT) {
+            if (first_short < 0) first_short = (int)r;
+        } else if (rc[r] != ROAR_OK) {
+            g_err = msg[r];
+            return rc[r];
+        }
+    }
+    if (first_short >= 0) {
+        g_err = msg[first_short];
+        return ROAR_ERR_SHORT;
+    }
+    return ROAR_OK;
+}
+
+// ---- pinned host memory for query / result blocks ----------------------------------------------------------------------
+
+void *roar_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)(bytes ? bytes : 1), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(ROAR_ERR_DEVICE, "pinned host allocation of %llu bytes failed", (unsigned long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void roar_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
 
 
 // ---- bipartite two-hop variant -------------------------------------------------
@@ -1430,18 +1613,20 @@ int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t 
         HIP_TRY(hipMalloc((void **)&idx->init_dev, (size_t)nq * n_init * sizeof(uint32_t)));
         idx->init_cap = nq * n_init;
     }
-    HIP_TRY(hipMemcpy(idx->init_dev, init_ids, (size_t)nq * n_init * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if ((e = stage_queries(idx, queries, nq, qstride_floats, k))) return e;
+    HIP_TRY(hipMemcpyAsync(idx->init_dev, init_ids, (size_t)nq * n_init * sizeof(uint32_t), hipMemcpyHostToDevice, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));  // init_ids may be a temporary of this call
+    const float *qdev = nullptr;
+    uint32_t qs = 0;
+    if ((e = stage_queries(idx, queries, nq, qstride_floats, k, &qdev, &qs))) return e;
     uint32_t *d_ids = idx->out_dev;
     float *d_dists = reinterpret_cast<float *>(d_ids + nq * k);
     uint32_t *d_cmps = d_ids + 2 * nq * k;
     uint32_t *d_hops = d_cmps + nq;
     uint32_t *d_scan = d_hops + nq;
     uint32_t *d_short = d_scan + nq;
-    e = roar_search_bipartite_batch_device(idx, idx->q_dev, nq, idx->dim_pad, k, L_pq, idx->init_dev, n_init, d_ids,
-                                           d_dists, d_cmps, d_hops, d_scan, d_short, nullptr);
+    e = roar_search_bipartite_batch_device(idx, qdev, nq, qs, k, L_pq, idx->init_dev, n_init, d_ids, d_dists, d_cmps,
+                                           d_hops, d_scan, d_short, idx->stream);
     if (e) return e;
-    HIP_TRY(hipDeviceSynchronize());
     return fetch_results(idx, nq, k, ids, dists, cmps, hops, nullptr);
 }
 

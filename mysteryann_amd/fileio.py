@@ -1,6 +1,6 @@
 """numpy readers / writers for the reference's on-disk formats (host-side helpers for tests,
 bench data generation and the Python mirror of the harness).  The product's own loaders are C++
-(mysteryann_amd/csrc/roar_host.cpp); these exist so Python can write inputs for them.
+(mysteryann_amd/csrc/roar_capi.cpp); these exist so Python can write inputs for them.
 
 Formats (all little-endian, no magic / padding), /root/reference citations:
   .fbin        u32 n; u32 d; f32[n*d]                         include/efanna2e/util.h:106-127,179-211

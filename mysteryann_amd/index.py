@@ -196,6 +196,37 @@ class IndexBipartite:
         capi.check(rc)
         return dict(ids=ids, dists=dists, cmps=cmps, hops=hops, scanned=scanned)
 
+    def Clone(self, device):
+        """Replica of this index (base rows + projection graph + options) on `device` (roar_clone_to_device)."""
+        other = IndexBipartite.__new__(IndexBipartite)
+        other._h = C.c_void_p()
+        other._lib = self._lib
+        capi.check(self._lib.roar_clone_to_device(self._h, int(device), C.byref(other._h)))
+        other.dimension, other.metric, other.device = self.dimension, self.metric, int(device)
+        other.need_normalize = self.need_normalize
+        other._keep = []
+        return other
+
+    @staticmethod
+    def SearchRoarGraphBatchMulti(replicas, queries, k, L_pq):
+        """One query block split over the replicas by query (roar_search_batch_multi): replica r searches rows
+        [r * nq / g, (r + 1) * nq / g).  -> dict(ids, dists, cmps, hops, scanned), same as SearchRoarGraphBatch."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        nq, qs = queries.shape
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        cmps = np.zeros(nq, np.uint32)
+        hops = np.zeros(nq, np.uint32)
+        scanned = np.zeros(nq, np.uint32)
+        hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+        lib = replicas[0]._lib
+        rc = lib.roar_search_batch_multi(hs, len(replicas), capi.f32p(queries), nq, qs, int(k), int(L_pq), capi.u32p(ids),
+                                         capi.f32p(dists), capi.u32p(cmps), capi.u32p(hops), capi.u32p(scanned))
+        if rc == capi.ERR_SHORT:
+            raise RoarError(rc, lib.roar_last_error().decode())
+        capi.check(rc)
+        return dict(ids=ids, dists=dists, cmps=cmps, hops=hops, scanned=scanned)
+
     def SearchRoarGraphBatchDevice(self, queries, k, L_pq, out=None, stream=None):
         """Device-resident form: `queries` is a CUDA/HIP torch tensor [nq, stride>=dim_padded];
         results are torch tensors in HBM; asynchronous on `stream` (torch stream or None)."""

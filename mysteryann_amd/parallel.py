@@ -1,7 +1,7 @@
 """Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
 
-Replicated index (BASELINE configs[3]): queries shard with no collective -- nothing to do here beyond
-`shard_range`.  Index-sharded (configs[4], base set larger than one GPU): every rank searches ALL
+Replicated index (BASELINE configs[3]): ONE query block, rank r searches rows `shard_range(nq, world, r)` of it with
+no collective in the data path (`gather_query_slices` only assembles the answer for checking).  Index-sharded (configs[4], base set larger than one GPU): every rank searches ALL
 queries on its own shard (own graph, local ids), local ids are rebased to global, the per-shard
 top-k lists are all-gathered (nq x k x 8 B per rank: latency bound on xGMI) and merged by
 (distance, id) with the HIP merge kernel.  Not in the reference; the oracle for it is
@@ -31,7 +31,31 @@ def rebase_ids(ids, offset):
     import numpy as np
 
     ids = np.asarray(ids)
-    return np.where(ids == INVALID, ids, ids + np.uint32(offset)).astype(ids.dtype)
+    if ids.dtype == np.int32:  # u32 bit patterns in a signed array (e.g. .cpu().numpy() of the device results): filler is -1
+        u = ids.view(np.uint32)
+        return np.where(u == INVALID, u, u + np.uint32(offset)).astype(np.uint32).view(np.int32)
+    return np.where(ids == INVALID, ids, ids + ids.dtype.type(offset)).astype(ids.dtype)
+
+
+def gather_query_slices(local, nq, group=None):
+    """Replicated configuration: every rank holds the rows `shard_range(nq, world, rank)` of a per-query result
+    (tensor [hi - lo, ...]); returns the whole [nq, ...] tensor on every rank.  Slices differ in length by at most one
+    row, so they are padded to the longest for the all-gather.  Checking / reporting only -- the search itself needs no
+    exchange."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    longest = max(shard_range(nq, world, r)[1] - shard_range(nq, world, r)[0] for r in range(world))
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty((nq,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        lo, hi = shard_range(nq, world, r)
+        out[lo:hi] = parts[r][:hi - lo]
+    return out
 
 
 def allgather_topk(ids, dists, group=None):

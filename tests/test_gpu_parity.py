@@ -565,6 +565,90 @@ def test_register_pool_boundaries_random_graphs(mode, built_lib):
     idx.close()
 
 
+@pytest.mark.parametrize("g", [2, 8])
+def test_one_batch_split_over_g_replicas_equals_single_launch(g, golden_dir, built_lib):
+    """BASELINE configs[3] host logic (roar_clone_to_device + roar_search_batch_multi): the index replicated g times
+    (all replicas on this box's one device), ONE query block split by query, every replica writing its own rows of
+    the caller's arrays.  The result must be the single-launch result, row for row, whatever g is -- including a
+    block that does not divide by g and one with fewer queries than replicas."""
+    from mysteryann_amd import index as mi
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.expected.npz"))
+    idx, q = _index("ip_200", golden_dir, 2)
+    reps = [idx] + [idx.Clone(0) for _ in range(g - 1)]
+    assert all(r.info("n") == idx.info("n") and r.info("nedges") == idx.info("nedges") for r in reps)
+    for L in (10, 50, 200):
+        one = idx.SearchRoarGraphBatch(q, K, L)
+        many = mi.IndexBipartite.SearchRoarGraphBatchMulti(reps, q, K, L)
+        for key in ("ids", "dists", "hops", "cmps", "scanned"):
+            assert np.array_equal(one[key], many[key]), (g, L, key)
+        assert np.array_equal(many["ids"], exp[f"ids_{L}"]) and np.array_equal(many["dists"], exp[f"dists_{L}"])
+    odd = q[: len(q) - 3]  # slices of unequal length
+    a = idx.SearchRoarGraphBatch(odd, K, 30)
+    b = mi.IndexBipartite.SearchRoarGraphBatchMulti(reps, odd, K, 30)
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["dists"], b["dists"])
+    few = q[:3]  # fewer queries than replicas: some slices are empty
+    a = idx.SearchRoarGraphBatch(few, K, 30)
+    b = mi.IndexBipartite.SearchRoarGraphBatchMulti(reps, few, K, 30)
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["hops"], b["hops"])
+    # a replica keeps the graph: its saved file equals the original's, byte for byte
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        reps[-1].SaveProjectionGraph(os.path.join(td, "r.index"))
+        assert open(os.path.join(td, "r.index"), "rb").read() == open(os.path.join(golden_dir, "ip_200.roar.index"), "rb").read()
+    for r in reps[1:]:
+        r.close()
+    idx.close()
+
+
+def test_multi_reports_short_results_and_mismatched_replicas(built_lib):
+    from mysteryann_amd import index as mi
+
+    n, d = 64, 16
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    off = np.zeros(n + 1, np.uint64)  # no edges at all: every query ends with one result
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(0, off, np.zeros(0, np.uint32))
+    rep = idx.Clone(0)
+    with pytest.raises(mi.RoarError, match="not enough results: 1, expected: 5"):
+        mi.IndexBipartite.SearchRoarGraphBatchMulti([idx, rep], base[:10], 5, 8)
+    other = mi.IndexBipartite(d, n - 1, 0, None)
+    other.SetBaseData(base[: n - 1])
+    with pytest.raises(mi.RoarError, match="does not hold the same index"):
+        mi.IndexBipartite.SearchRoarGraphBatchMulti([idx, other], base[:10], 1, 8)
+    for x in (idx, rep, other):
+        x.close()
+
+
+def test_pinned_query_block_is_read_in_place(golden_dir, built_lib):
+    """roar_host_alloc memory (what the facade's load_data / data_align return) is read by the kernel where it lies;
+    results equal those of an ordinary pageable block, and rows strided wider than the dimension work too."""
+    import ctypes as C
+
+    from mysteryann_amd import capi
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.expected.npz"))
+    idx, q = _index("ip_200", golden_dir, 2)
+    lib = capi.lib()
+    nq, d = q.shape
+    for stride in (d, d + 8):
+        ptr = lib.roar_host_alloc(nq * stride * 4)
+        assert ptr
+        blk = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(nq, stride))
+        blk[:] = 7.5  # columns past the dimension must not matter
+        blk[:, :d] = q
+        ids = np.zeros((nq, K), np.uint32)
+        dists = np.zeros((nq, K), np.float32)
+        hops = np.zeros(nq, np.uint32)
+        capi.check(lib.roar_search_batch(idx._h, C.cast(ptr, C.POINTER(C.c_float)), nq, stride, K, 50, capi.u32p(ids),
+                                         capi.f32p(dists), None, capi.u32p(hops), None))
+        assert np.array_equal(ids, exp["ids_50"]) and np.array_equal(dists, exp["dists_50"]) and np.array_equal(hops, exp["hops_50"])
+        lib.roar_host_free(ptr)
+    idx.close()
+
+
 def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
     """BASELINE configs[0] shape through the file-based drop-in path: SIFT-like 128-d L2 set written as
     .fbin / .ibin / graph index, searched by the C++ harness (mysteryann_amd/csrc/test_search_roargraph,
@@ -588,7 +672,8 @@ def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
     fileio.write_fbin(paths["query.fbin"], q)
     fileio.write_gt(paths["gt.ibin"], gt_i, gt_d)
     fileio.write_graph(paths["roar.index"], ep, adj)
-    for extra in ([], ["--visited", "exact"], ["--per_query", "-T", "4"]):
+    # --devices 0,0,0: the index replicated three times (all on this box's device), the query block split by query
+    for extra in ([], ["--visited", "exact"], ["--per_query", "-T", "4"], ["--devices", "0,0,0"]):
         out = subprocess.run([exe, "--data_type", "float", "--dist", "l2", "--base_data_path", paths["base.fbin"],
                               "--query_path", paths["query.fbin"], "--gt_path", paths["gt.ibin"],
                               "--projection_index_save_path", paths["roar.index"], "--L_pq", "20", "100", "--k", "10",

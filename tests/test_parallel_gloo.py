@@ -73,9 +73,24 @@ def _worker(rank, world, port, tmp):
     ref = t.clone()
     dist.broadcast(ref, 0)
     assert torch.equal(t, ref)
-    # ---- replicated index, sharded queries: disjoint contiguous slices that cover all queries
-    qlo, qhi = parallel.shard_range(nq, world, rank)
-    cover = torch.zeros(nq, dtype=torch.int64)
+    # ---- replicated index, ONE query block split by query (BASELINE configs[3]): rank r searches its slice of the same
+    # block on the same graph; the gathered slices must be the single-process answer, row for row
+    goff = np.zeros(n + 1, np.uint64)
+    grng = np.random.default_rng(7)
+    goff[1:] = np.cumsum(grng.integers(4, 24, n))
+    gnbrs = grng.integers(0, n, int(goff[-1])).astype(np.uint32)
+    nq2 = 25  # not divisible by the world size: slices of 12 and 13 rows
+    q2 = rng.standard_normal((nq2, d)).astype(np.float32)
+    qlo, qhi = parallel.shard_range(nq2, world, rank)
+    mine = oracle.search_batch(base, goff, gnbrs, 3, q2[qlo:qhi], k, L, 0)
+    ids_g = parallel.gather_query_slices(torch.from_numpy(mine["ids"].astype(np.int64)), nq2)
+    d_g = parallel.gather_query_slices(torch.from_numpy(mine["dists"]), nq2)
+    hops_g = parallel.gather_query_slices(torch.from_numpy(mine["hops"].astype(np.int64)), nq2)
+    whole = oracle.search_batch(base, goff, gnbrs, 3, q2, k, L, 0)
+    assert np.array_equal(ids_g.numpy(), whole["ids"].astype(np.int64))
+    assert np.array_equal(d_g.numpy(), whole["dists"])
+    assert np.array_equal(hops_g.numpy(), whole["hops"].astype(np.int64))
+    cover = torch.zeros(nq2, dtype=torch.int64)
     cover[qlo:qhi] = 1
     dist.all_reduce(cover)
     assert bool((cover == 1).all())
@@ -94,4 +109,6 @@ def test_rebase_keeps_short_result_filler():
     assert parallel.rebase_ids(a, 10).tolist() == [[11, 12, 0xFFFFFFFF]]
     t = torch.tensor([[1, 2, -1]], dtype=torch.int32)
     assert parallel.rebase_ids(t, 10).tolist() == [[11, 12, -1]]
+    b = np.array([[1, 2, -1]], np.int32)  # the same bit patterns in a signed numpy array
+    assert parallel.rebase_ids(b, 10).tolist() == [[11, 12, -1]]
     assert parallel.shard_range(10, 4, 0) == (0, 2) and parallel.shard_range(10, 4, 3) == (7, 10)

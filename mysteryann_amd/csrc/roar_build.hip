@@ -16,8 +16,20 @@
 //                 the nearest result (the pivot) is linked to the other results, which is the idea
 //                 of the projected bipartite graph in its simplest form
 //   rescue        nodes nobody points to are forced into a row of one of their own neighbours
+//
+// Determinism.  No kernel here appends to an adjacency row through an atomic cursor.  Every step that links nodes
+// writes its edges as PROPOSALS -- u64 keys (destination row << 32 | new neighbour) at slots fixed by the list that
+// makes them -- the proposals of a batch are radix-sorted (rocPRIM) and applied by one thread per destination row in
+// ascending neighbour id: skip what the row already holds, append while the row has room, drop (or, for the orphan
+// rescue, overwrite the last slot) beyond.  Searches return bit-identical results whatever the scheduling, so two builds
+// of the same data make the same graph (roar_get_info "graph_hash"; tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <cstring>
+#include <new>
+
+#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -91,38 +103,97 @@ __global__ void seed_rows_kernel(uint32_t *adj, uint32_t S, uint32_t seed, uint3
     row[0] = deg;
 }
 
-// link nodes a..a+count-1 (thread per node): out-edges = its M search results, reverse edges appended.
-// relink != 0: the node already has a row (seed): overwrite its first slots, keep what was appended.
-__global__ void link_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count,
-                            const uint32_t *__restrict__ res, uint32_t M, uint32_t ep, uint32_t *indeg, int relink) {
+constexpr u64 NO_PROP = ~0ull;
+__device__ __forceinline__ u64 make_prop(uint32_t dst, uint32_t src) { return ((u64)dst << 32) | src; }
+
+// link nodes a..a+count-1 (thread per node): out-edges = its M search results, and the reverse edges; 2 M proposal slots
+// per node.  (relink: the node is a seed whose random links are being replaced -- its new out-edges are proposed like
+// any other, the random ones stay until the row is cut.)
+__global__ void link_kernel(uint32_t a, uint32_t count, const uint32_t *__restrict__ res, uint32_t M, uint32_t ep, int relink,
+                            u64 *__restrict__ props) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = a + i;
-    if (!relink && v == ep) return;  // the entry point was linked with the seeds
-    uint32_t *row = adj + (u64)v * S;
-    uint32_t deg = 0;
+    u64 *out = props + (u64)i * 2 * M;
     for (uint32_t j = 0; j < M; ++j) {
         const uint32_t u = res[(u64)i * M + j];
-        if (u == 0xFFFFFFFFu || u == v) continue;
-        row[1 + deg++] = u;
-        atomicAdd(&indeg[u], 1u);
-        // reverse edge u -> v while row u has room
-        uint32_t *urow = adj + (u64)u * S;
-        const uint32_t old = atomicAdd(&urow[0], 1u);
-        if (old < max_deg) {
-            urow[1 + old] = v;
-            atomicAdd(&indeg[v], 1u);
+        const bool ok = u != 0xFFFFFFFFu && u != v && (relink || v != ep);  // the entry point was linked with the seeds
+        out[2 * j] = ok ? make_prop(v, u) : NO_PROP;
+        out[2 * j + 1] = ok ? make_prop(u, v) : NO_PROP;
+    }
+}
+
+// One thread per run of equal destinations in the sorted proposal array: merge the run into row `dst`.
+// overflow_last != 0: a full row takes the proposal in its last slot (orphan rescue); else it is dropped.
+__global__ void apply_props_kernel(uint32_t *adj, uint32_t S, uint32_t cap, const u64 *__restrict__ props, u64 nprops,
+                                   uint32_t *indeg, int overflow_last) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nprops) return;
+    const u64 key = props[i];
+    if (key == NO_PROP) return;
+    const uint32_t dst = (uint32_t)(key >> 32);
+    if (i > 0 && (uint32_t)(props[i - 1] >> 32) == dst) return;  // not the head of its run
+    uint32_t *row = adj + (u64)dst * S;
+    uint32_t deg = row[0] < cap ? row[0] : cap;
+    u64 prev = NO_PROP;
+    for (u64 j = i; j < nprops; ++j) {
+        const u64 kj = props[j];
+        if (kj == NO_PROP || (uint32_t)(kj >> 32) != dst) break;
+        if (kj == prev) continue;  // the same edge proposed twice
+        prev = kj;
+        const uint32_t src = (uint32_t)kj;
+        if (src == dst) continue;
+        bool have = false;
+        for (uint32_t q = 0; q < deg && !have; ++q) have = row[1 + q] == src;
+        if (have) continue;
+        if (deg < cap) {
+            row[1 + deg++] = src;
+            if (indeg) atomicAdd(&indeg[src], 1u);
+        } else if (overflow_last) {
+            const uint32_t victim = row[cap];
+            row[cap] = src;
+            if (indeg) {
+                atomicAdd(&indeg[src], 1u);
+                atomicSub(&indeg[victim], 1u);
+            }
         } else {
-            atomicSub(&urow[0], 1u);
+            break;  // the row is full and stays as it is: nothing further in this run can change it
         }
     }
-    if (relink) {
-        if (row[0] < deg) row[0] = deg;
-    } else {
-        // reverse edges may already have been appended to this row by batch mates? No: v is not in the
-        // graph while its batch is searched, nobody can have v as a result.
-        row[0] = deg;
+    row[0] = deg;
+}
+
+// 64-bit order-independent-across-rows hash of the graph: sum over rows of mix(row id, degree, neighbours in order)
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+__global__ void graph_hash_kernel(const uint32_t *__restrict__ adj, uint32_t S, u64 n, uint32_t ep, u64 *out) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 h = 0;
+    if (v < n) {
+        const uint32_t *row = adj + v * S;
+        const uint32_t deg = row[0];
+        h = mix64(v * 0x9E3779B97F4A7C15ull + deg);
+        for (uint32_t j = 0; j < deg; ++j) h = mix64(h ^ ((u64)row[1 + j] + 0x632BE59BD9B4E019ull * (j + 1)));
+        if (v == 0) h += mix64(0xE9ull + ep);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
+// rows of stride S_old -> rows of stride S_new (<= S_old) in place, ascending row order: row v's new position never
+// lies beyond its old one, and a block only moves rows whose old words nobody before it still has to read ... so the
+// copy goes through a second buffer instead (a 10 M-row graph is 1.6 GB at stride 40 words).
+__global__ void restride_rows_kernel(const uint32_t *__restrict__ src, uint32_t S_old, uint32_t *__restrict__ dst,
+                                     uint32_t S_new, u64 n) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 v = w / S_new;
+    const uint32_t j = (uint32_t)(w % S_new);
+    if (v >= n) return;
+    const uint32_t deg = src[v * S_old];
+    dst[v * S_new + j] = (j <= deg && j < S_old) ? src[v * S_old + j] : 0u;
 }
 
 // Occlusion-prune-and-link, one wave per list.  Two ways to name the node that receives the edges:
@@ -135,17 +206,14 @@ __global__ void link_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_
 // Rule (PruneBiSearchBaseGetBase, :1612-1694 / PruneProjectionBaseSearchCandidates, :1846-1940):
 // candidates are ordered by their base-to-base distance to the target; one is kept unless an already
 // kept one is closer to it than the target is; optionally back-filled with the nearest leftovers up to
-// Mp.  target -> kept edges are appended (row capacity cap_t), kept -> target edges too (cap_r).
-// In pivot mode a full target row refreshes one of its projection slots (rows are
-// [phase-1 edges | projection edges], base_deg[v] is where the projection part starts).
+// Mp.  The edges target -> kept and kept -> target leave as proposals (2 x 63 slots per list), see apply_props_kernel.
 template <bool IP>
-__global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r,
-                                                       const uint32_t *__restrict__ base_deg,
+__global__ void __launch_bounds__(64) prune_link_kernel(const uint32_t *adj, uint32_t S, uint32_t cap_t,
                                                        const float *__restrict__ base, u64 ld, uint32_t dim,
                                                        uint32_t count, const uint32_t *__restrict__ res,
-                                                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg,
-                                                       uint32_t salt, long long target_base, int skip_existing,
-                                                       int backfill, uint32_t skip_node, int flags) {
+                                                       uint32_t M, uint32_t C, uint32_t Mp, long long target_base,
+                                                       int skip_existing, int backfill, uint32_t skip_node, int flags,
+                                                       u64 *__restrict__ props) {
     extern __shared__ __align__(16) float rows[];  // (ncand + 1) x (dim + 1) floats, row 0 = target
     const int lane = threadIdx.x;
     const uint32_t rs = dim + 1;
@@ -154,12 +222,18 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
     for (uint32_t t = blockIdx.x; t < count; t += gridDim.x) {
         const uint32_t *r = res + (u64)t * M;
         const uint32_t target = tmode ? (uint32_t)(target_base + t) : r[0];
-        if (target == 0xFFFFFFFFu || target == skip_node) continue;
+        if (target == 0xFFFFFFFFu || target == skip_node) {
+            if (lane > 0 && (uint32_t)lane <= ncand) {
+                u64 *out = props + ((u64)t * ncand + (uint32_t)(lane - 1)) * 2;
+                out[0] = out[1] = NO_PROP;
+            }
+            continue;
+        }
         uint32_t myid = 0xFFFFFFFFu;
         if (lane == 0) myid = target;
         else if ((uint32_t)lane <= ncand) myid = r[tmode ? lane - 1 : lane];
         if (lane > 0 && myid == target) myid = 0xFFFFFFFFu;
-        uint32_t *trow = adj + (u64)target * S;
+        const uint32_t *trow = adj + (u64)target * S;
         if (skip_existing && lane > 0 && myid != 0xFFFFFFFFu) {
             const uint32_t td = trow[0] < cap_t ? trow[0] : cap_t;
             bool have = false;
@@ -226,37 +300,11 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
                 nkept++;
             }
         }
-        // target -> kept, kept -> target
-        if (kept) {
-            const uint32_t pd = trow[0] < cap_t ? trow[0] : cap_t;
-            bool have = false;
-            for (uint32_t q = 0; q < pd; ++q) have |= trow[1 + q] == myid;
-            if (!have) {
-                const uint32_t old = atomicAdd(&trow[0], 1u);
-                if (old < cap_t) {
-                    trow[1 + old] = myid;
-                    atomicAdd(&indeg[myid], 1u);
-                } else {
-                    atomicSub(&trow[0], 1u);
-                    if (!tmode && base_deg) {  // row full: refresh a projection slot
-                        const uint32_t b0 = base_deg[target] < cap_t ? base_deg[target] : cap_t;
-                        if (b0 < cap_t) trow[1 + b0 + mix32(myid ^ salt ^ (t * 0x9E3779B9u)) % (cap_t - b0)] = myid;
-                    }
-                }
-            }
-            uint32_t *urow = adj + (u64)myid * S;
-            const uint32_t ud = urow[0] < cap_r ? urow[0] : cap_r;
-            have = false;
-            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == target;
-            if (!have) {
-                const uint32_t old = atomicAdd(&urow[0], 1u);
-                if (old < cap_r) {
-                    urow[1 + old] = target;
-                    atomicAdd(&indeg[target], 1u);
-                } else {
-                    atomicSub(&urow[0], 1u);
-                }
-            }
+        // target -> kept and kept -> target, as proposals: slot pair of lane l of list t (lanes 1..63)
+        if (lane > 0 && (uint32_t)lane <= ncand) {
+            u64 *out = props + ((u64)t * ncand + (uint32_t)(lane - 1)) * 2;
+            out[0] = kept ? make_prop(target, myid) : NO_PROP;
+            out[1] = kept ? make_prop(myid, target) : NO_PROP;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -264,42 +312,24 @@ __global__ void __launch_bounds__(64) prune_link_kernel(uint32_t *adj, uint32_t 
     }
 }
 
-// connectivity supplement (cf. the reference's "connectivity enhancement", src/index_bipartite.cpp:
-// 1188-1262): node v was searched in the finished graph with its own vector under the index
-// metric; link v <-> each of its first Kc results where rows have room (thread per node).
-__global__ void supply_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count,
-                              const uint32_t *__restrict__ res, uint32_t M, uint32_t Kc, uint32_t *indeg) {
+// connectivity supplement without pruning (cf. the reference's "connectivity enhancement", src/index_bipartite.cpp:
+// 1188-1262): node v was searched in the finished graph with its own vector under the index metric; v <-> each of
+// its first Kc results, as proposals (2 Kc slots per node).
+__global__ void supply_kernel(uint32_t a, uint32_t count, const uint32_t *__restrict__ res, uint32_t M, uint32_t Kc,
+                              u64 *__restrict__ props) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t v = a + i;
-    uint32_t *vrow = adj + (u64)v * S;
+    u64 *out = props + (u64)i * 2 * Kc;
     uint32_t done = 0;
     for (uint32_t j = 0; j < M && done < Kc; ++j) {
         const uint32_t u = res[(u64)i * M + j];
         if (u == 0xFFFFFFFFu || u == v) continue;
+        out[2 * done] = make_prop(u, v);
+        out[2 * done + 1] = make_prop(v, u);
         done++;
-        uint32_t *urow = adj + (u64)u * S;
-        {   // u -> v
-            const uint32_t ud = urow[0] < max_deg ? urow[0] : max_deg;
-            bool have = false;
-            for (uint32_t q = 0; q < ud; ++q) have |= urow[1 + q] == v;
-            if (!have) {
-                const uint32_t old = atomicAdd(&urow[0], 1u);
-                if (old < max_deg) { urow[1 + old] = v; atomicAdd(&indeg[v], 1u); }
-                else atomicSub(&urow[0], 1u);
-            }
-        }
-        {   // v -> u
-            const uint32_t vd = vrow[0] < max_deg ? vrow[0] : max_deg;
-            bool have = false;
-            for (uint32_t q = 0; q < vd; ++q) have |= vrow[1 + q] == u;
-            if (!have) {
-                const uint32_t old = atomicAdd(&vrow[0], 1u);
-                if (old < max_deg) { vrow[1 + old] = u; atomicAdd(&indeg[u], 1u); }
-                else atomicSub(&vrow[0], 1u);
-            }
-        }
     }
+    for (; done < Kc; ++done) out[2 * done] = out[2 * done + 1] = NO_PROP;
 }
 
 __global__ void snapshot_degree_kernel(const uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n, uint32_t *base_deg) {
@@ -315,27 +345,20 @@ __global__ void clamp_degree_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg,
     if (adj[v * S] > max_deg) adj[v * S] = max_deg;
 }
 
-// nodes without an in-edge: push v into the row of its r-th own neighbour (append, else last slot)
-__global__ void rescue_kernel(uint32_t *adj, uint32_t S, uint32_t max_deg, u64 n, uint32_t ep, uint32_t r,
-                              uint32_t *indeg, uint32_t *orphans) {
+// nodes without an in-edge propose themselves to the row of their r-th own neighbour (one slot per node; applied with
+// overflow_last: a full row gives up its last slot)
+__global__ void rescue_kernel(const uint32_t *adj, uint32_t S, u64 n, uint32_t ep, uint32_t r, const uint32_t *indeg,
+                              uint32_t *orphans, u64 *__restrict__ props) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || v == ep || indeg[v] != 0) return;
-    atomicAdd(orphans, 1u);
-    const uint32_t *row = adj + v * S;
-    const uint32_t deg = row[0];
-    if (deg == 0) return;
-    const uint32_t u = row[1 + (r % deg)];
-    uint32_t *urow = adj + (u64)u * S;
-    const uint32_t old = atomicAdd(&urow[0], 1u);
-    if (old < max_deg) {
-        urow[1 + old] = (uint32_t)v;
-    } else {
-        atomicSub(&urow[0], 1u);
-        const uint32_t victim = urow[max_deg];
-        urow[max_deg] = (uint32_t)v;  // replaces the last slot
-        if (victim != (uint32_t)v) atomicSub(&indeg[victim], 1u);
+    if (v >= n) return;
+    u64 p = NO_PROP;
+    if (v != ep && indeg[v] == 0) {
+        atomicAdd(orphans, 1u);
+        const uint32_t *row = adj + v * S;
+        const uint32_t deg = row[0];
+        if (deg) p = make_prop(row[1 + (r % deg)], (uint32_t)v);
     }
-    atomicAdd(&indeg[v], 1u);
+    props[v] = p;
 }
 
 // final clean-up of a built graph: drop self loops and repeated neighbours (first occurrence kept,
@@ -401,7 +424,7 @@ __global__ void __launch_bounds__(64) cut_rows_kernel(uint32_t *adj, uint32_t S,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float t = wave_sum(acc[u]);
-                if (lane == 0 && j0 + u < deg) keys[j0 + u] = ((u64)f2ord_b(IP ? -t : t) << 32) | (j0 + u);
+                if (lane == 0 && j0 + u < deg) keys[j0 + u] = ((u64)f2ord_b(IP ? -t : t) << 32) | ids_l[j0 + u];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -411,7 +434,7 @@ __global__ void __launch_bounds__(64) cut_rows_kernel(uint32_t *adj, uint32_t S,
             const u64 key = keys[i];
             uint32_t rank = 0;
             for (uint32_t q = 0; q < deg; ++q) rank += keys[q] < key ? 1u : 0u;
-            if (rank < keep) row[1 + rank] = ids_l[i];
+            if (rank < keep) row[1 + rank] = (uint32_t)key;  // ties between equal distances fall to the smaller id
         }
         if (lane == 0) {
             row[0] = keep;
@@ -518,21 +541,76 @@ int roar_bk_seed(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t
     return (int)hipGetLastError();
 }
 
-int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
-                 uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream) {
-    if (count == 0) return 0;
-    hipLaunchKernelGGL(link_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, adj, S, max_deg, a,
-                       count, res, M, ep, indeg, relink);
+// ---- proposal workspace: two key buffers + the radix sort's scratch ------------------------------------------------
+struct RoarBuildWs {
+    u64 *a = nullptr, *b = nullptr;
+    uint64_t cap = 0;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+};
+
+int roar_bk_ws_create(uint64_t max_props, void **out) {
+    RoarBuildWs *w = new (std::nothrow) RoarBuildWs();
+    if (!w) return (int)hipErrorOutOfMemory;
+    w->cap = max_props;
+    hipError_t e = hipMalloc((void **)&w->a, (size_t)max_props * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&w->b, (size_t)max_props * 8);
+    if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, w->tmp_bytes, w->a, w->b, (size_t)max_props, 0, 64, nullptr);
+    if (e == hipSuccess) e = hipMalloc(&w->tmp, w->tmp_bytes ? w->tmp_bytes : 16);
+    if (e != hipSuccess) {
+        (void)hipFree(w->a); (void)hipFree(w->b); (void)hipFree(w->tmp);
+        delete w;
+        return (int)e;
+    }
+    *out = w;
+    return 0;
+}
+
+void roar_bk_ws_destroy(void *ws) {
+    RoarBuildWs *w = (RoarBuildWs *)ws;
+    if (!w) return;
+    (void)hipFree(w->a); (void)hipFree(w->b); (void)hipFree(w->tmp);
+    delete w;
+}
+
+uint64_t roar_bk_ws_capacity(void *ws) { return ws ? ((RoarBuildWs *)ws)->cap : 0; }
+unsigned long long *roar_bk_ws_keys(void *ws) { return ws ? (unsigned long long *)((RoarBuildWs *)ws)->a : nullptr; }
+
+// sort the proposals in w->a[0, nprops) and merge them into the rows (ascending destination, ascending neighbour)
+int roar_bk_apply(void *ws, uint64_t nprops, uint32_t *adj, uint32_t S, uint32_t cap, uint32_t *indeg, int overflow_last,
+                  void *stream) {
+    RoarBuildWs *w = (RoarBuildWs *)ws;
+    if (!w || nprops > w->cap) return (int)hipErrorInvalidValue;
+    if (nprops == 0) return 0;
+    size_t tb = w->tmp_bytes;
+    hipError_t e = rocprim::radix_sort_keys(w->tmp, tb, w->a, w->b, (size_t)nprops, 0, 64, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(apply_props_kernel, dim3((uint32_t)((nprops + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
+                       cap, w->b, (u64)nprops, indeg, overflow_last);
     return (int)hipGetLastError();
 }
 
-int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
-                       const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
-                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
-                       int skip_existing, int backfill, uint32_t skip_node, int flags, void *stream) {
+int roar_bk_link(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+                 uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream) {
     if (count == 0) return 0;
+    RoarBuildWs *w = (RoarBuildWs *)ws;
+    const uint64_t np = (uint64_t)count * 2 * M;
+    if (!w || np > w->cap) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(link_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, count, res, M, ep,
+                       relink, w->a);
+    return roar_bk_apply(ws, np, adj, S, max_deg, indeg, 0, stream);
+}
+
+int roar_bk_prune_link(void *ws, uint32_t *adj, uint32_t S, uint32_t cap, const float *base, uint64_t ld, uint32_t dim,
+                       int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C, uint32_t Mp,
+                       uint32_t *indeg, long long target_base, int skip_existing, int backfill, uint32_t skip_node, int flags,
+                       void *stream) {
+    if (count == 0) return 0;
+    RoarBuildWs *w = (RoarBuildWs *)ws;
     const uint32_t ncand = target_base >= 0 ? C : C - 1;
     if (ncand > 63 || ncand == 0) return (int)hipErrorInvalidValue;
+    const uint64_t np = (uint64_t)count * ncand * 2;
+    if (!w || np > w->cap) return (int)hipErrorInvalidValue;
     const uint32_t lds = (ncand + 1) * (dim + 1) * sizeof(float);
     const uint32_t grid = count < 8192u ? count : 8192u;
     const void *fn = metric_ip ? (const void *)prune_link_kernel<true> : (const void *)prune_link_kernel<false>;
@@ -541,22 +619,25 @@ int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r
         if (e != hipSuccess) return (int)e;
     }
     if (metric_ip)
-        hipLaunchKernelGGL(prune_link_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
-                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
-                           backfill, skip_node, flags);
+        hipLaunchKernelGGL(prune_link_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap, base, (u64)ld,
+                           dim, count, res, M, C, Mp, target_base, skip_existing, backfill, skip_node, flags, w->a);
     else
-        hipLaunchKernelGGL(prune_link_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap_t, cap_r,
-                           base_deg, base, (u64)ld, dim, count, res, M, C, Mp, indeg, salt, target_base, skip_existing,
-                           backfill, skip_node, flags);
-    return (int)hipGetLastError();
+        hipLaunchKernelGGL(prune_link_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, adj, S, cap, base, (u64)ld,
+                           dim, count, res, M, C, Mp, target_base, skip_existing, backfill, skip_node, flags, w->a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return roar_bk_apply(ws, np, adj, S, cap, indeg, 0, stream);
 }
 
-int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+int roar_bk_supply(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                    uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream) {
-    if (count == 0) return 0;
-    hipLaunchKernelGGL(supply_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, adj, S, max_deg, a,
-                       count, res, M, Kc, indeg);
-    return (int)hipGetLastError();
+    if (count == 0 || Kc == 0) return 0;
+    RoarBuildWs *w = (RoarBuildWs *)ws;
+    const uint64_t np = (uint64_t)count * 2 * Kc;
+    if (!w || np > w->cap) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(supply_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, count, res, M, Kc,
+                       w->a);
+    return roar_bk_apply(ws, np, adj, S, max_deg, indeg, 0, stream);
 }
 
 int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
@@ -572,12 +653,31 @@ int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void 
     return (int)hipGetLastError();
 }
 
-int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
+int roar_bk_rescue(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
                    uint32_t *orphans, void *stream) {
+    RoarBuildWs *w = (RoarBuildWs *)ws;
+    if (!w || n > w->cap) return (int)hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(orphans, 0, 4, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(rescue_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S,
-                       max_deg, (u64)n, ep, r, indeg, orphans);
+    hipLaunchKernelGGL(rescue_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S, (u64)n, ep,
+                       r, indeg, orphans, w->a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return roar_bk_apply(ws, n, adj, S, max_deg, indeg, 1, stream);  // a full row gives up its last slot
+}
+
+int roar_bk_graph_hash(const uint32_t *adj, uint32_t S, uint64_t n, uint32_t ep, unsigned long long *out_dev, void *stream) {
+    hipError_t e = hipMemsetAsync(out_dev, 0, 8, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(graph_hash_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, S, (u64)n,
+                       ep, (u64 *)out_dev);
+    return (int)hipGetLastError();
+}
+
+int roar_bk_restride(const uint32_t *src, uint32_t S_old, uint32_t *dst, uint32_t S_new, uint64_t n, void *stream) {
+    const uint64_t words = n * S_new;
+    hipLaunchKernelGGL(restride_rows_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       S_old, dst, S_new, (u64)n);
     return (int)hipGetLastError();
 }
 }

@@ -21,19 +21,21 @@ extern "C" {  // roar_build.hip
 int roar_bk_entry_point(const float *base, uint64_t ld, uint32_t dim, uint64_t n, float *sums_dev,
                         unsigned long long *best_dev, void *stream);
 int roar_bk_seed(uint32_t *adj, uint32_t S, uint32_t seed, uint32_t ep, uint32_t M, void *stream);
-int roar_bk_link(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+int roar_bk_ws_create(uint64_t max_props, void **out);
+void roar_bk_ws_destroy(void *ws);
+int roar_bk_link(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                  uint32_t M, uint32_t ep, uint32_t *indeg, int relink, void *stream);
-int roar_bk_prune_link(uint32_t *adj, uint32_t S, uint32_t cap_t, uint32_t cap_r, const uint32_t *base_deg,
-                       const float *base, uint64_t ld, uint32_t dim, int metric_ip, uint32_t count, const uint32_t *res,
-                       uint32_t M, uint32_t C, uint32_t Mp, uint32_t *indeg, uint32_t salt, long long target_base,
-                       int skip_existing, int backfill, uint32_t skip_node, int flags, void *stream);
-int roar_bk_supply(uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
+int roar_bk_prune_link(void *ws, uint32_t *adj, uint32_t S, uint32_t cap, const float *base, uint64_t ld, uint32_t dim,
+                       int metric_ip, uint32_t count, const uint32_t *res, uint32_t M, uint32_t C, uint32_t Mp,
+                       uint32_t *indeg, long long target_base, int skip_existing, int backfill, uint32_t skip_node, int flags,
+                       void *stream);
+int roar_bk_supply(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint32_t a, uint32_t count, const uint32_t *res,
                    uint32_t M, uint32_t Kc, uint32_t *indeg, void *stream);
 int roar_bk_snapshot_degree(const uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t *base_deg,
                             void *stream);
 int roar_bk_clamp(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
-int roar_bk_rescue(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r, uint32_t *indeg,
-                   uint32_t *orphans, void *stream);
+int roar_bk_rescue(void *ws, uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, uint32_t ep, uint32_t r,
+                   uint32_t *indeg, uint32_t *orphans, void *stream);
 int roar_bk_trim(uint32_t *adj, uint32_t S, uint32_t max_deg, const uint32_t *base_deg, uint64_t n, uint32_t min_proj,
                  uint32_t keep_base, void *stream);
 int roar_bk_dedupe(uint32_t *adj, uint32_t S, uint32_t max_deg, uint64_t n, void *stream);
@@ -41,6 +43,8 @@ int roar_bk_cut_rows(uint32_t *adj, uint32_t S, uint32_t cap, uint32_t keep, con
                      int metric_ip, uint64_t n, uint32_t *base_deg, void *stream);
 int roar_bk_degree_stats(const uint32_t *adj, uint32_t S, uint64_t n, unsigned long long *sum_dev, uint32_t *max_dev,
                          void *stream);
+int roar_bk_graph_hash(const uint32_t *adj, uint32_t S, uint64_t n, uint32_t ep, unsigned long long *out_dev, void *stream);
+int roar_bk_restride(const uint32_t *src, uint32_t S_old, uint32_t *dst, uint32_t S_new, uint64_t n, void *stream);
 }
 
 extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim,
@@ -86,6 +90,8 @@ struct roar_index {
     uint32_t *adj = nullptr;
     uint32_t adj_stride = 0, ep = 0, max_deg = 0;
     uint64_t gn = 0, nedges = 0;
+    uint64_t graph_hash = 0;  // of the device rows (degree + neighbours in order, per row) and the entry point
+    bool graph_hash_valid = false;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_nbrs;
     // bipartite graph (base nodes [0, n), training-query nodes [n, bp_n)): CSR in HBM + host copy
@@ -170,6 +176,7 @@ void free_graph(roar_index *idx) {
     idx->h_off.clear();
     idx->h_nbrs.clear();
     idx->gn = idx->nedges = 0;
+    idx->graph_hash_valid = false;
 }
 
 void free_bipartite(roar_index *idx) {
@@ -890,10 +897,12 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (bp->learn_knn_dev && (C < 2 || C > 64 || Mp == 0)) return fail(ROAR_ERR_ARG, "bad M_sq / M_pj for the kNN lists");
     uint32_t *res_ids = nullptr, *indeg = nullptr, *scratch = nullptr, *base_deg = nullptr;
     float *res_d = nullptr, *sums = nullptr;
+    void *ws = nullptr;  // edge proposals of one batch: two u64 slots per candidate lane (or per linked result)
     const int saved_mode = idx->visited_mode;
     auto cleanup = [&]() {  // every exit below goes through here: workspaces freed, search state restored
         (void)hipFree(res_ids); (void)hipFree(res_d); (void)hipFree(indeg); (void)hipFree(sums); (void)hipFree(scratch);
         (void)hipFree(base_deg);
+        roar_bk_ws_destroy(ws);
         idx->visited_mode = saved_mode;
         idx->building = false;
         idx->ip = idx->metric != ROAR_METRIC_L2;
@@ -913,6 +922,14 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     HIP_TRYC(hipMalloc((void **)&base_deg, (size_t)n * 4));
     HIP_TRYC(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
     HIP_TRYC(hipMalloc((void **)&scratch, 16));
+    {
+        const uint64_t per_list = 2ull * std::max<uint64_t>(std::max<uint64_t>(K, M), 1);
+        const int rc = roar_bk_ws_create(std::max<uint64_t>(cap * per_list, n), &ws);
+        if (rc != 0) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "out of device memory for the builder's edge proposals: %s", hipGetErrorString((hipError_t)rc));
+        }
+    }
 #define BK_TRY(call)                                                                        \
     do {                                                                                    \
         int rc_ = (call);                                                                   \
@@ -944,12 +961,11 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         const uint64_t cnt = std::min<uint64_t>(std::min<uint64_t>(max_batch, a), n - a);
         if (C1) {  // insert with occlusion pruning of the node's own search results
             if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
-            BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
-                                      idx->ip ? 1 : 0, (uint32_t)cnt, res_ids, C1, C1, M, indeg, 0, (long long)a, 0, 1,
-                                      idx->ep, 0, nullptr));
+            BK_TRY(roar_bk_prune_link(ws, idx->adj, S, base_cap, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0,
+                                      (uint32_t)cnt, res_ids, C1, C1, M, indeg, (long long)a, 0, 1, idx->ep, 0, nullptr));
         } else {
             if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, M, L_build))) { cleanup(); return e; }
-            BK_TRY(roar_bk_link(idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
+            BK_TRY(roar_bk_link(ws, idx->adj, S, base_cap, (uint32_t)a, (uint32_t)cnt, res_ids, M, idx->ep, indeg, 0, nullptr));
         }
         a += cnt;
     }
@@ -957,11 +973,11 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (!skeleton) {
     } else if (C1) {
         if ((e = search(idx->base, seed, idx->ld, C1, std::max(L_build, C1)))) { cleanup(); return e; }
-        BK_TRY(roar_bk_prune_link(idx->adj, S, base_cap, base_cap, nullptr, idx->base, idx->ld, idx->dim_pad,
-                                  idx->ip ? 1 : 0, seed, res_ids, C1, C1, M, indeg, 0, 0ll, 1, 1, 0xFFFFFFFFu, 0, nullptr));
+        BK_TRY(roar_bk_prune_link(ws, idx->adj, S, base_cap, idx->base, idx->ld, idx->dim_pad, idx->ip ? 1 : 0, seed, res_ids,
+                                  C1, C1, M, indeg, 0ll, 1, 1, 0xFFFFFFFFu, 0, nullptr));
     } else {
         if ((e = search(idx->base, seed, idx->ld, M, L_build))) { cleanup(); return e; }
-        BK_TRY(roar_bk_link(idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
+        BK_TRY(roar_bk_link(ws, idx->adj, S, base_cap, 0, seed, res_ids, M, idx->ep, indeg, 1, nullptr));
     }
     idx->ip = saved_ip;
     BK_TRY(roar_bk_clamp(idx->adj, S, base_cap, n, nullptr));
@@ -984,9 +1000,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     if (bp->learn_knn_dev && bp->n_knn) {
         for (uint64_t a = 0; a < bp->n_knn; a += max_batch) {
             const uint64_t cnt = std::min<uint64_t>(max_batch, bp->n_knn - a);
-            BK_TRY(roar_bk_prune_link(idx->adj, S, proj_cap, proj_cap, base_deg, idx->base, idx->ld, idx->dim_pad,
-                                      proj_ip, (uint32_t)cnt, bp->learn_knn_dev + a * C, C, C, Mp, indeg, 0x7654321u,
-                                      -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
+            BK_TRY(roar_bk_prune_link(ws, idx->adj, S, proj_cap, idx->base, idx->ld, idx->dim_pad, proj_ip, (uint32_t)cnt,
+                                      bp->learn_knn_dev + a * C, C, C, Mp, indeg, -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
         BK_TRY(cut_rows());
@@ -999,9 +1014,8 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                 cleanup();
                 return e;
             }
-            BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, base_deg, idx->base, idx->ld, idx->dim_pad,
-                                      proj_ip, (uint32_t)cnt, res_ids, C, C, Mp, indeg, 0x1234567u * (r + 1), -1ll, 0,
-                                      1, 0xFFFFFFFFu, proj_flags, nullptr));
+            BK_TRY(roar_bk_prune_link(ws, idx->adj, S, max_degree, idx->base, idx->ld, idx->dim_pad, proj_ip, (uint32_t)cnt,
+                                      res_ids, C, C, Mp, indeg, -1ll, 0, 1, 0xFFFFFFFFu, proj_flags, nullptr));
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
         }
         BK_TRY(cut_rows());
@@ -1017,12 +1031,12 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
                                                                    : max_batch, n - a);
             if (C3) {  // pruned supply edges: candidates = the node's search results not yet in its row
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, C3, std::max(Ls, C3)))) { cleanup(); return e; }
-                BK_TRY(roar_bk_prune_link(idx->adj, S, max_degree, max_degree, nullptr, idx->base, idx->ld, idx->dim_pad,
-                                          (bp->supply_mode == 1) ? 0 : (idx->ip ? 1 : 0), (uint32_t)cnt, res_ids, C3, C3, Ks, indeg, 0,
+                BK_TRY(roar_bk_prune_link(ws, idx->adj, S, max_degree, idx->base, idx->ld, idx->dim_pad,
+                                          (bp->supply_mode == 1) ? 0 : (idx->ip ? 1 : 0), (uint32_t)cnt, res_ids, C3, C3, Ks, indeg,
                                           (long long)a, 1, 0, 0xFFFFFFFFu, (bp->supply_mode == 2) ? 3 : 0, nullptr));
             } else {
                 if ((e = search(idx->base + a * idx->ld, cnt, idx->ld, Ks + 1, Ls))) { cleanup(); return e; }
-                BK_TRY(roar_bk_supply(idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
+                BK_TRY(roar_bk_supply(ws, idx->adj, S, max_degree, (uint32_t)a, (uint32_t)cnt, res_ids, Ks + 1, Ks, indeg, nullptr));
             }
             a += cnt;
             BK_TRY(roar_bk_clamp(idx->adj, S, max_degree, n, nullptr));
@@ -1035,7 +1049,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     // its graph -- trimming it on the SIFT shape drops recall from 0.95 to 0.42 at L_pq = 100)
     if (bp->trim_min_proj && bp->phase1_l2 && saved_ip) BK_TRY(roar_bk_trim(idx->adj, S, max_degree, base_deg, n, bp->trim_min_proj, bp->trim_keep_base, nullptr));
     for (uint32_t r = 0; r < 8; ++r) {
-        BK_TRY(roar_bk_rescue(idx->adj, S, max_degree, n, idx->ep, r, indeg, scratch, nullptr));
+        BK_TRY(roar_bk_rescue(ws, idx->adj, S, max_degree, n, idx->ep, r, indeg, scratch, nullptr));
         uint32_t orphans = 0;
         HIP_TRYC(hipMemcpy(&orphans, scratch, 4, hipMemcpyDeviceToHost));
         if (orphans == 0) break;
@@ -1046,6 +1060,21 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     HIP_TRYC(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));
     idx->nedges = st[0];
     idx->max_deg = (uint32_t)(st[1] & 0xFFFFFFFFu);
+    // rows collected proposals in a room of max_degree words; what is left needs round_up(longest row + 1, 32) words
+    // per row (T2I-10M, room 384 / keep 128: 16.6 GB -> 6.4 GB)
+    {
+        const uint32_t S_new = round_up(idx->max_deg + 1, 32);
+        if (S_new < S) {
+            uint32_t *compact = nullptr;
+            HIP_TRYC(hipMalloc((void **)&compact, ((size_t)n * S_new + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
+            BK_TRY(roar_bk_restride(idx->adj, S, compact, S_new, n, nullptr));
+            HIP_TRYC(hipMemsetAsync(compact + (size_t)n * S_new, 0, ADJ_SLACK_WORDS * sizeof(uint32_t), nullptr));
+            HIP_TRYC(hipDeviceSynchronize());
+            (void)hipFree(idx->adj);
+            idx->adj = compact;
+            idx->adj_stride = S_new;
+        }
+    }
 #undef BK_TRY
 #undef HIP_TRYC
     cleanup();
@@ -1841,6 +1870,21 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;
+    else if (k == "graph_hash") {
+        if (!idx->adj || idx->gn == 0) return fail(ROAR_ERR_ARG, "no graph loaded");
+        if (!idx->graph_hash_valid) {
+            HIP_TRY(hipSetDevice(idx->device));
+            unsigned long long *h_dev = nullptr, h = 0;
+            HIP_TRY(hipMalloc((void **)&h_dev, 8));
+            int rc = roar_bk_graph_hash(idx->adj, idx->adj_stride, idx->gn, idx->ep, h_dev, nullptr);
+            hipError_t he = rc == 0 ? hipMemcpy(&h, h_dev, 8, hipMemcpyDeviceToHost) : (hipError_t)rc;
+            (void)hipFree(h_dev);
+            if (he != hipSuccess) return fail(ROAR_ERR_DEVICE, "graph hash failed: %s", hipGetErrorString(he));
+            idx->graph_hash = h;
+            idx->graph_hash_valid = true;
+        }
+        *value = (int64_t)idx->graph_hash;
+    }
     else if (k == "last_grid") *value = idx->last_grid;
     else if (k == "last_lds_bytes") *value = idx->last_lds;
     else if (k == "last_vis_entries") *value = idx->last_vis_entries;

@@ -649,6 +649,30 @@ def test_pinned_query_block_is_read_in_place(golden_dir, built_lib):
     idx.close()
 
 
+def test_two_builds_of_the_same_data_make_the_same_graph(built_lib):
+    """The builder appends no edge through an atomic cursor (proposals are sorted, then applied in order), so the graph
+    is a function of the data: two builds of a 200 k-point T2I-shape set have the same 64-bit adjacency hash, rows are
+    compacted to the longest row, and a third build with another projection depth hashes differently."""
+    import torch
+
+    from mysteryann_amd import index as mi, synth
+
+    n, d = 200_000, 200
+    base, q, learn = synth.t2i_torch(n, 256, d, n_learn=n)
+    hashes, saved = [], []
+    for L_learn in (128, 128, 96):
+        idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
+        idx.SetBaseData(base)
+        idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128, L_learn=L_learn)
+        torch.cuda.synchronize()
+        hashes.append(idx.info("graph_hash"))
+        assert idx.info("adj_stride") == (idx.info("max_degree") + 1 + 31) // 32 * 32 <= 160
+        saved.append(idx.SearchRoarGraphBatchDevice(q, 10, 30)["ids"].cpu().numpy())
+        idx.close()
+    assert hashes[0] == hashes[1] and hashes[0] != hashes[2], [hex(h & (2**64 - 1)) for h in hashes]
+    assert np.array_equal(saved[0], saved[1])
+
+
 def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
     """BASELINE configs[0] shape through the file-based drop-in path: SIFT-like 128-d L2 set written as
     .fbin / .ibin / graph index, searched by the C++ harness (mysteryann_amd/csrc/test_search_roargraph,

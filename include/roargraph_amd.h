@@ -127,21 +127,24 @@ typedef struct roar_build_params {
 } roar_build_params;
 int roar_build_graph(roar_index *idx, const roar_build_params *params);
 
-/* ---- BuildRoarGraph, reference shape (first version) ------------------------------
+/* ---- BuildRoarGraph ---------------------------------------------------------------
  * IndexBipartite::LoadLearnBaseKNN + BuildRoarGraph  src/index_bipartite.cpp:2622-2639, 143-233; CLI
- * tests/test_build_roargraph.cpp:105-137.  `learn_knn`: host array [n_learn][K] of the nearest base ids of
- * every training query, nearest first (the "learn base knn" file: u32 n; u32 K; ids).  Steps follow
- * LinkProjection (:1043-1277) on the device: entry point (:2004-2041); projection -- pivot = list[0],
- * the next M_sq - 1 candidates occlusion-pruned to M_pjbp (:1612-1694), rows and reverse edges capped at
- * M_pjbp; connectivity enhancement -- every node searched in the graph so far (L_pjpq), its 63 nearest
- * results occlusion-pruned to M_pjbp (:1846-1940) and linked both ways, up to 2 M_pjbp supply edges per
- * row; nodes are walked in growing batches instead of one by one.  Deviations, measured on the restated
- * reference builder (oracle/roar_builder_oracle.c) to move recall-vs-cmps by < 5 % each: M_sq is clamped
- * to 63, a full row drops a reverse edge instead of re-pruning, supply candidates are the 63 nearest
- * expanded nodes.  The reference's builder is nondeterministic (OpenMP + per-node locks), so parity here
- * is degree statistics + the recall-vs-L curve (tests/test_gpu_parity.py), not bytes. */
+ * tests/test_build_roargraph.cpp:105-137.  `learn_knn`: [n_learn][K] nearest base ids of every training query,
+ * nearest first (the "learn base knn" file: u32 n; u32 K; ids; host array, or HBM for the _device form -- e.g. straight
+ * from roar_exact_knn_device).  The steps of LinkProjection (:1043-1277) in a batch-synchronous form (what maps to
+ * what: csrc/roar_rgbuild.hip): entry point (:2004-2041); projection -- pivot = list[0], the next M_sq - 1 (<= 254)
+ * candidates pruned by PruneBiSearchBaseGetBase (:1612-1694) to M_pjbp, the pivot's row = the list of its last training
+ * query, reverse edges with the re-prune of a full row (:1391-1432, :1527-1610); connectivity enhancement -- every node
+ * searched in the supply graph (L_pjpq), the WHOLE final pool of that search pruned by
+ * PruneProjectionBaseSearchCandidates (:1846-1940), reverse supply edges with cap 2 M_pjbp (:1352-1389, :1434-1525),
+ * nodes walked in growing batches instead of one by one; merge of up to 2 M_pjbp supply edges (:1262-1275).
+ * Deterministic (the reference is not: OpenMP + per-node locks), so parity with it is degree statistics + the
+ * recall-vs-distance-evaluations curve (tests/test_gpu_parity.py against tests/golden/builder_yardstick_200000.json, the
+ * restated reference builder's curve), not bytes. */
 int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                          uint32_t M_pjbp, uint32_t L_pjpq);
+int roar_build_roargraph_device(roar_index *idx, const uint32_t *learn_knn_dev, uint64_t n_learn, uint32_t K, uint32_t M_sq,
+                                uint32_t M_pjbp, uint32_t L_pjpq);
 
 /* ---- search ---------------------------------------------------------------------------------
  * IndexBipartite::SearchRoarGraph  src/index_bipartite.cpp:2311-2420, batched over nq queries
@@ -287,6 +290,15 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value);
  * speculative adjacency fetches that were used, adjacency round trips paid, then wave 0's scoring passes: cycles
  * {issuing loads, waiting + FMAs, reduction + packing}, number of passes, candidates that reached the merge; 3 spare. */
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
+
+/* Known-answer surface for NeighborPriorityQueue (include/efanna2e/neighbor.h:138-223): replays a scripted sequence on
+ * the device with the queue routines of the search kernels -- ops[i] == 0: insert(ids[i], dists[i]) (:150-183), else
+ * closest_unexpanded() if has_unexpanded_node() (:185-194) -- and returns the state after every op,
+ * snap[i] = {size, cur, (id, distance bits, flag) x capacity} (u32[n_ops][2 + 3 capacity], unused cells 0), the layout
+ * of tests/golden/pq_trace.npz.  pool_in_registers: 0 = the LDS pool (any L_pq), 1 = the register pool (L_pq <= 64).
+ * Host arrays; capacity <= 64. */
+int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids, const float *dists,
+                     int pool_in_registers, uint32_t *snap);
 
 /* InitVisitedListPool(num_threads)  include/index_bipartite.h:133: sizes the EXACT-mode tag pool
  * (one u8[n] list per resident wave).  Optional: done lazily by the first EXACT search. */

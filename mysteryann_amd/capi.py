@@ -25,7 +25,7 @@ SYMBOLS = [
     "roar_load_bipartite_file", "roar_save_bipartite_file", "roar_set_bipartite_csr", "roar_get_bipartite_csr",
     "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
     "roar_search_bipartite_batch_device", "roar_last_profile", "roar_clone_to_device", "roar_search_batch_multi",
-    "roar_host_alloc", "roar_host_free",
+    "roar_host_alloc", "roar_host_free", "roar_queue_trace", "roar_build_roargraph_device",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
     l.roar_get_graph_csr.argtypes = [vp, u32p, u64p, u64p, u64p, u32p]
     l.roar_build_graph.argtypes = [vp, C.POINTER(BuildParams)]
     l.roar_build_roargraph.argtypes = [vp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    l.roar_build_roargraph_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     l.roar_search_batch.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, u32p, u32p]
     l.roar_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                            vp, vp]
@@ -107,6 +108,7 @@ def lib():
     l.roar_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
     l.roar_search_batch_multi.argtypes = [C.POINTER(vp), C.c_uint32, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp,
                                           u32p, u32p, u32p]
+    l.roar_queue_trace.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), u32p, fp, C.c_int, u32p]
     l.roar_host_alloc.argtypes = [C.c_uint64]
     l.roar_host_alloc.restype = vp
     l.roar_host_free.argtypes = [vp]

@@ -47,6 +47,29 @@ int roar_bk_graph_hash(const uint32_t *adj, uint32_t S, uint64_t n, uint32_t ep,
 int roar_bk_restride(const uint32_t *src, uint32_t S_old, uint32_t *dst, uint32_t S_new, uint64_t n, void *stream);
 }
 
+extern "C" {  // roar_rgbuild.hip
+int roar_rg_list_prune(const float *base, uint64_t ld, uint32_t dim, int ip, int mode, const uint32_t *lists, uint32_t K,
+                       uint32_t C, uint32_t count, uint32_t t0, const uint32_t *rows, uint32_t S, const uint32_t *grows,
+                       uint32_t Sg, uint32_t M, uint32_t only_longer_than, uint32_t *out, uint32_t *cnt, void *stream);
+int roar_rg_supply_prune(const float *base, uint64_t ld, uint32_t dim, int ip, const uint32_t *res_ids, const float *res_d,
+                         uint32_t Lres, uint32_t count, uint32_t t0, const uint32_t *grows, uint32_t Sg, uint32_t M,
+                         unsigned long long *keyscratch, uint32_t scratch_waves, uint32_t *out, uint32_t *cnt, void *stream);
+int roar_rg_last_list(const uint32_t *lists, uint32_t K, uint32_t count, uint32_t sq0, uint32_t *last, void *stream);
+int roar_rg_set_rows(uint32_t *rows, uint32_t S, const uint32_t *lists, uint32_t K, uint32_t count, uint32_t sq0, uint32_t t0,
+                     int by_pivot, const uint32_t *last, const uint32_t *out, const uint32_t *cnt, uint32_t M,
+                     unsigned long long *props, void *stream);
+int roar_rg_props_from_rows(const uint32_t *rows, uint32_t S, uint64_t v0, uint64_t count, uint32_t M, unsigned long long *props,
+                            void *stream);
+int roar_rg_reverse(const float *base, uint64_t ld, uint32_t dim, int ip, uint32_t *rows, uint32_t S, uint32_t cap, uint32_t M,
+                    int list_backfill, unsigned long long *keys_in, unsigned long long *keys_out, uint64_t nprops, void *sort_tmp,
+                    size_t sort_tmp_bytes, uint32_t *heads, uint32_t *heads_sorted, uint32_t *nheads_dev, void *stream);
+int roar_rg_sort_tmp_bytes(uint64_t max_keys, size_t *bytes);
+int roar_rg_merge_rows(const uint32_t *grows, uint32_t Sg, const uint32_t *srows, uint32_t Ss, uint32_t *adj, uint32_t Sf,
+                       uint64_t n, uint32_t M, void *stream);
+int roar_rg_copy_rows(const uint32_t *src, uint32_t Ssrc, uint32_t *dst, uint32_t Sdst, uint64_t n, void *stream);
+}
+extern "C" int roar_launch_queue_trace(uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids,
+                                       const float *dists, int form, uint32_t *snap, void *stream);
 extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim,
                             int ip, uint32_t k, uint32_t cap, void *cand, void *cursor, void *tau, void *bnorm,
                             void *overflow_dev, uint32_t *ids, float *dists, uint32_t *overflowed, void *stream);
@@ -1081,45 +1104,185 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     return ROAR_OK;
 }
 
+// BuildRoarGraph in its batch-synchronous device form (kernels and the mapping to the reference's steps: roar_rgbuild.hip)
+int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint64_t n_learn, uint32_t K, uint32_t M_sq,
+                                uint32_t M_pjbp, uint32_t L_pjpq) {
+    if (!idx || !lists_dev || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
+    if (M_pjbp == 0 || M_pjbp > 128) return fail(ROAR_ERR_ARG, "M_pjbp must be in 1..128");
+    if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
+    if (idx->n >= (1ull << 31) || n_learn >= (1ull << 32) - 1) return fail(ROAR_ERR_ARG, "too many points or training queries");
+    const uint32_t C = std::min<uint32_t>(std::min<uint32_t>(M_sq ? M_sq : K, K), 255u);  // candidates per training query
+    if (C < 2) return fail(ROAR_ERR_ARG, "M_sq must be at least 2");
+    const uint32_t M = M_pjbp;
+    const uint32_t Lp = std::max<uint32_t>(L_pjpq, M);
+    if (8ull * (Lp + 1) > 120 * 1024) return fail(ROAR_ERR_ARG, "L_pjpq = %u does not fit the search kernel's LDS pool", L_pjpq);
+    int e = use_device(idx);
+    if (e) return e;
+    std::lock_guard<std::mutex> guard(idx->mu);
+    free_graph(idx);
+    const uint64_t n = idx->n;
+    const int ip = idx->ip ? 1 : 0;
+    const uint32_t Sg = round_up(M + 1, 32), Ss = round_up(2 * M + 1, 32), Sf = round_up(3 * M + 1, 32);
+    const uint64_t batch_lists = std::min<uint64_t>(n_learn, 1u << 20);      // projection: training queries per batch
+    const uint64_t batch_nodes = std::min<uint64_t>(n, 1u << 16);            // connectivity: nodes per batch (k = L_pjpq results each)
+    const uint64_t max_props = std::max<uint64_t>(std::max<uint64_t>(batch_lists, batch_nodes) * M, std::min<uint64_t>(n, 1u << 20) * M);
+    const uint32_t scratch_waves = 4096;
+
+    uint32_t *grows = nullptr, *srows = nullptr, *final_adj = nullptr, *last = nullptr, *out = nullptr, *cnt = nullptr;
+    uint32_t *heads = nullptr, *heads_sorted = nullptr, *nheads_dev = nullptr, *res_ids = nullptr, *scratch = nullptr;
+    float *res_d = nullptr, *sums = nullptr;
+    unsigned long long *props_a = nullptr, *props_b = nullptr, *keyscratch = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    const int saved_mode = idx->visited_mode;
+    auto cleanup = [&]() {
+        (void)hipFree(grows); (void)hipFree(srows); (void)hipFree(final_adj); (void)hipFree(last); (void)hipFree(out);
+        (void)hipFree(cnt); (void)hipFree(heads); (void)hipFree(heads_sorted); (void)hipFree(nheads_dev); (void)hipFree(res_ids);
+        (void)hipFree(res_d); (void)hipFree(sums); (void)hipFree(scratch); (void)hipFree(props_a); (void)hipFree(props_b);
+        (void)hipFree(keyscratch); (void)hipFree(sort_tmp);
+        idx->visited_mode = saved_mode;
+        idx->building = false;
+    };
+    auto drop_graph = [&]() {  // a failed build leaves no half-made graph behind (idx->adj may alias one of the buffers above)
+        idx->adj = nullptr;
+        idx->gn = idx->nedges = 0;
+    };
+#define RG_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            drop_graph();                                                                   \
+            cleanup();                                                                      \
+            return fail(ROAR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));           \
+        }                                                                                   \
+    } while (0)
+#define RG_TRY(call)                                                                        \
+    do {                                                                                    \
+        int rc_ = (call);                                                                   \
+        if (rc_ != 0) {                                                                     \
+            drop_graph();                                                                   \
+            cleanup();                                                                      \
+            return fail(ROAR_ERR_DEVICE, "%s: %s", #call, hipGetErrorString((hipError_t)rc_)); \
+        }                                                                                   \
+    } while (0)
+    RG_HIP(hipMalloc((void **)&grows, ((size_t)n * Sg + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(hipMemset(grows, 0, ((size_t)n * Sg + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(hipMalloc((void **)&srows, ((size_t)n * Ss + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(hipMemset(srows, 0, ((size_t)n * Ss + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(hipMalloc((void **)&last, (size_t)n * 4));
+    RG_HIP(hipMemset(last, 0, (size_t)n * 4));
+    const uint64_t max_lists = std::max<uint64_t>(std::max<uint64_t>(batch_lists, batch_nodes), std::min<uint64_t>(n, 1u << 20));
+    RG_HIP(hipMalloc((void **)&out, (size_t)max_lists * M * 4));
+    RG_HIP(hipMalloc((void **)&cnt, (size_t)max_lists * 4));
+    RG_HIP(hipMalloc((void **)&props_a, (size_t)max_props * 8));
+    RG_HIP(hipMalloc((void **)&props_b, (size_t)max_props * 8));
+    RG_HIP(hipMalloc((void **)&heads, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
+    RG_HIP(hipMalloc((void **)&heads_sorted, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
+    RG_HIP(hipMalloc((void **)&nheads_dev, 4));
+    RG_TRY(roar_rg_sort_tmp_bytes(max_props, &sort_tmp_bytes));
+    RG_HIP(hipMalloc(&sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16));
+    RG_HIP(hipMalloc((void **)&res_ids, (size_t)batch_nodes * Lp * 4));
+    RG_HIP(hipMalloc((void **)&res_d, (size_t)batch_nodes * Lp * 4));
+    RG_HIP(hipMalloc((void **)&keyscratch, (size_t)scratch_waves * Lp * 8));
+    RG_HIP(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
+    RG_HIP(hipMalloc((void **)&scratch, 16));
+
+    // CalculateProjectionep (:2004-2041)
+    RG_TRY(roar_bk_entry_point(idx->base, idx->ld, idx->dim_pad, n, sums, (unsigned long long *)scratch, nullptr));
+    unsigned long long best = 0;
+    RG_HIP(hipMemcpy(&best, scratch, 8, hipMemcpyDeviceToHost));
+    idx->ep = (uint32_t)(best & 0xFFFFFFFFu);
+
+    auto reverse = [&](uint32_t *rows, uint32_t S, uint32_t cap, int list_backfill, uint64_t nprops) -> int {
+        return roar_rg_reverse(idx->base, idx->ld, idx->dim_pad, ip, rows, S, cap, M, list_backfill, props_a, props_b, nprops,
+                               sort_tmp, sort_tmp_bytes, heads, heads_sorted, nheads_dev, nullptr);
+    };
+    // ---- projection (:1059-1129)
+    for (uint64_t a = 0; a < n_learn; a += batch_lists)
+        RG_TRY(roar_rg_last_list(lists_dev + a * K, K, (uint32_t)std::min<uint64_t>(batch_lists, n_learn - a), (uint32_t)a, last, nullptr));
+    for (uint64_t a = 0; a < n_learn; a += batch_lists) {
+        const uint32_t c = (uint32_t)std::min<uint64_t>(batch_lists, n_learn - a);
+        RG_TRY(roar_rg_list_prune(idx->base, idx->ld, idx->dim_pad, ip, 0, lists_dev + a * K, K, C, c, 0, nullptr, 0, nullptr, 0, M,
+                                  0, out, cnt, nullptr));
+        RG_TRY(roar_rg_set_rows(grows, Sg, lists_dev + a * K, K, c, (uint32_t)a, 0, 1, last, out, cnt, M, props_a, nullptr));
+        RG_TRY(reverse(grows, Sg, M, 1, (uint64_t)c * M));
+    }
+    for (uint64_t v0 = 0; v0 < n; v0 += (1u << 20)) {  // :1096-1099: every node's row proposes the node once more
+        const uint64_t c = std::min<uint64_t>(1u << 20, n - v0);
+        RG_TRY(roar_rg_props_from_rows(grows, Sg, v0, c, M, props_a, nullptr));
+        RG_TRY(reverse(grows, Sg, M, 1, c * M));
+    }
+    // ---- connectivity enhancement (:1183-1262): the supply graph starts as the projection graph and is what gets searched
+    RG_TRY(roar_rg_copy_rows(grows, Sg, srows, Ss, n, nullptr));
+    idx->adj = srows;
+    idx->adj_stride = Ss;
+    idx->gn = n;
+    idx->max_deg = 2 * M;
+    idx->visited_mode = ROAR_VISITED_LDS;
+    idx->building = true;
+    for (uint64_t a = 0; a < n;) {
+        // the reference walks the nodes one by one, each seeing the supply edges of the ones before it: small batches first
+        const uint64_t c = std::min<uint64_t>(std::min<uint64_t>(batch_nodes, std::max<uint64_t>(a / 2, 64)), n - a);
+        int rc = roar_search_batch_device(idx, idx->base + a * idx->ld, c, idx->ld, Lp, Lp, res_ids, res_d, nullptr, nullptr,
+                                          nullptr, nullptr, nullptr);
+        if (rc) {
+            const std::string keep = g_err;
+            drop_graph();
+            cleanup();
+            g_err = keep;
+            return rc;
+        }
+        RG_TRY(roar_rg_supply_prune(idx->base, idx->ld, idx->dim_pad, ip, res_ids, res_d, Lp, (uint32_t)c, (uint32_t)a, grows, Sg,
+                                    M, keyscratch, scratch_waves, out, cnt, nullptr));
+        RG_TRY(roar_rg_set_rows(srows, Ss, nullptr, 0, (uint32_t)c, 0, (uint32_t)a, 0, nullptr, out, cnt, M, props_a, nullptr));
+        RG_TRY(reverse(srows, Ss, 2 * M, 0, c * M));
+        a += c;
+    }
+    idx->building = false;
+    idx->visited_mode = saved_mode;
+    for (uint64_t v0 = 0; v0 < n; v0 += (1u << 20)) {  // :1230-1258: supply rows longer than M are pruned once more
+        const uint32_t c = (uint32_t)std::min<uint64_t>(1u << 20, n - v0);
+        RG_TRY(roar_rg_list_prune(idx->base, idx->ld, idx->dim_pad, ip, 1, nullptr, 0, 0, c, (uint32_t)v0, srows, Ss, grows, Sg, M, M,
+                                  out, cnt, nullptr));
+        RG_TRY(roar_rg_set_rows(srows, Ss, nullptr, 0, c, 0, (uint32_t)v0, 0, nullptr, out, cnt, M, props_a, nullptr));
+    }
+    // ---- merge (:1262-1275)
+    RG_HIP(hipMalloc((void **)&final_adj, ((size_t)n * Sf + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(hipMemset(final_adj, 0, ((size_t)n * Sf + ADJ_SLACK_WORDS) * 4));
+    RG_TRY(roar_rg_merge_rows(grows, Sg, srows, Ss, final_adj, Sf, n, M, nullptr));
+    RG_TRY(roar_bk_degree_stats(final_adj, Sf, n, (unsigned long long *)scratch, scratch + 2, nullptr));
+    unsigned long long st[2] = {0, 0};
+    RG_HIP(hipMemcpy(st, scratch, 16, hipMemcpyDeviceToHost));
+    idx->adj = final_adj;
+    final_adj = nullptr;  // owned by the index now
+    idx->adj_stride = Sf;
+    idx->nedges = st[0];
+    idx->max_deg = (uint32_t)(st[1] & 0xFFFFFFFFu);
+    idx->graph_hash_valid = false;
+#undef RG_HIP
+#undef RG_TRY
+    cleanup();
+    return ROAR_OK;
+}
+
 int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                          uint32_t M_pjbp, uint32_t L_pjpq) {
     if (!idx || !learn_knn || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
-    if (M_pjbp == 0 || M_pjbp > 63 || 3 * M_pjbp > 1023) return fail(ROAR_ERR_ARG, "M_pjbp must be in 1..63");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
-    int e = use_device(idx);
-    if (e) return e;
-    // the projection kernel holds one candidate per lane: M_sq is clamped to 63 (restated-builder ablation:
-    // M_sq 100 -> 63 moves recall at equal distance evaluations by < 0.2 %)
-    const uint32_t C = std::min<uint32_t>(std::min<uint32_t>(M_sq ? M_sq : K, K), 63u);
-    if (C < 2) return fail(ROAR_ERR_ARG, "M_sq must be at least 2");
+    const uint32_t C = std::min<uint32_t>(std::min<uint32_t>(M_sq ? M_sq : K, K), 255u);
     for (uint64_t i = 0; i < n_learn; ++i)
         for (uint32_t j = 0; j < C; ++j)
             if (learn_knn[i * K + j] >= idx->n) return fail(ROAR_ERR_FORMAT, "learn base knn file error");
-    std::vector<uint32_t> packed((size_t)n_learn * C);
-    for (uint64_t i = 0; i < n_learn; ++i) memcpy(&packed[i * C], learn_knn + i * K, C * sizeof(uint32_t));
+    int e = use_device(idx);
+    if (e) return e;
     uint32_t *lists_dev = nullptr;
-    HIP_TRY(hipMalloc((void **)&lists_dev, packed.size() * sizeof(uint32_t)));
-    hipError_t he = hipMemcpy(lists_dev, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    HIP_TRY(hipMalloc((void **)&lists_dev, (size_t)n_learn * K * sizeof(uint32_t)));
+    hipError_t he = hipMemcpy(lists_dev, learn_knn, (size_t)n_learn * K * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (he != hipSuccess) {
         (void)hipFree(lists_dev);
         return fail(ROAR_ERR_DEVICE, "upload of the kNN lists failed: %s", hipGetErrorString(he));
     }
-    roar_build_params bp;
-    memset(&bp, 0, sizeof bp);
-    bp.M = 1;
-    bp.base_cap = 1;
-    bp.max_degree = 3 * M_pjbp;  // projection row (M) + merged supply edges (2M), src/index_bipartite.cpp:1262-1275
-    bp.L_build = 8;
-    bp.M_sq = C;
-    bp.M_pj = M_pjbp;
-    bp.L_learn = C;
-    bp.n_knn = n_learn;
-    bp.learn_knn_dev = lists_dev;
-    bp.supply_k = M_pjbp;
-    bp.supply_cand = 63;
-    bp.supply_L = std::max<uint32_t>(L_pjpq, 63);
-    bp.no_skeleton = 1;
-    e = roar_build_graph(idx, &bp);
+    e = roar_build_roargraph_device(idx, lists_dev, n_learn, K, M_sq, M_pjbp, L_pjpq);
     (void)hipFree(lists_dev);
     return e;
 }
@@ -1800,6 +1963,35 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
     HIP_TRY(hipSetDevice(device));
     int rc = roar_launch_merge_topk(nshards, nq, k, ids_dev, dists_dev, out_ids_dev, out_dists_dev, hip_stream);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "merge kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return ROAR_OK;
+}
+
+int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids, const float *dists,
+                     int pool_in_registers, uint32_t *snap) {
+    if (!ops || !ids || !dists || !snap || capacity == 0 || capacity > 64)
+        return fail(ROAR_ERR_ARG, "queue trace: capacity 1..64 and non-null arrays");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(ROAR_ERR_DEVICE, "no HIP device available; this library has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    if (n_ops == 0) return ROAR_OK;
+    const size_t row = 2 + 3 * (size_t)capacity;
+    uint8_t *d_ops = nullptr;
+    uint32_t *d_ids = nullptr, *d_snap = nullptr;
+    float *d_d = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_ops); (void)hipFree(d_ids); (void)hipFree(d_d); (void)hipFree(d_snap); };
+    hipError_t e = hipMalloc((void **)&d_ops, n_ops);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ids, (size_t)n_ops * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_d, (size_t)n_ops * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_snap, (size_t)n_ops * row * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_ops, ops, n_ops, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_ids, ids, (size_t)n_ops * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, dists, (size_t)n_ops * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = (hipError_t)roar_launch_queue_trace(capacity, n_ops, d_ops, d_ids, d_d, pool_in_registers ? 1 : 0, d_snap, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(snap, d_snap, (size_t)n_ops * row * 4, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(ROAR_ERR_DEVICE, "queue trace failed: %s", hipGetErrorString(e));
     return ROAR_OK;
 }
 

@@ -441,6 +441,76 @@ __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, con
 }
 
 
+// Known-answer surface for the queue (A4): replays a scripted NeighborPriorityQueue sequence -- op 0 = insert(id, dist)
+// (neighbor.h:150-183), op 1 = closest_unexpanded() if has_unexpanded_node() (:185-194) -- on one wave with the very
+// routines the search kernels use, and writes the state after every op as the reference harness of
+// tests/golden/pq_trace.npz does: [size, cur, (id, distance bits, flag) x capacity].  form 0: pool in LDS
+// (merge_candidates + the cursor scan), form 1: pool in a register pair (merge_regpool + ballot select; capacity <= 64).
+__global__ void __launch_bounds__(64) roar_queue_trace_kernel(uint32_t capacity, uint32_t n_ops, const uint8_t *__restrict__ ops,
+                                                             const uint32_t *__restrict__ ids, const float *__restrict__ dists,
+                                                             int form, uint32_t *__restrict__ snap) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *pool = reinterpret_cast<u64 *>(smem);             // capacity + 1
+    u64 *ck = pool + ((capacity + 2) & ~1u);               // one candidate
+    const int lane = threadIdx.x;
+    const uint32_t L = capacity, row = 2 + 3 * capacity;
+    u64 pk = ~0ull;
+    uint32_t psize = 0, cur = 0;
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        if (ops[i] == 0) {
+            if (lane == 0) ck[0] = make_key(dists[i], ids[i]);
+            wave_sync();
+            if (psize == 0) {  // the kernels always start from a scored entry point: first insert by hand
+                if (form) pk = lane == 0 ? ck[0] : ~0ull;
+                else if (lane == 0) pool[0] = ck[0];
+                psize = 1;
+                cur = 0;
+                wave_sync();
+            } else if (form) {
+                merge_regpool(pk, psize, ck, 1, L, pool, lane);
+            } else {
+                merge_candidates(pool, ck, 1, L, psize, cur, lane);
+            }
+        } else if (form) {
+            const u64 um = __ballot((uint32_t)lane < psize && !(pk & 1ull));
+            if (um && lane == __ffsll((long long)um) - 1) pk |= 1ull;
+        } else if (cur < psize) {
+            const u64 e = pool[cur];
+            if (lane == 0) pool[cur] = e | 1ull;
+            wave_sync();
+            uint32_t found = psize;
+            for (uint32_t c = cur + 1; c < psize; c += 64) {
+                const uint32_t kidx = c + (uint32_t)lane;
+                const bool unf = kidx < psize && !(pool[kidx] & 1ull);
+                const u64 b = __ballot(unf);
+                if (b) {
+                    found = c + (uint32_t)__ffsll((long long)b) - 1u;
+                    break;
+                }
+            }
+            cur = found;
+        }
+        if (form) {  // the register form has no cursor: it is the first entry that is not expanded
+            const u64 um = __ballot((uint32_t)lane < psize && !(pk & 1ull));
+            cur = um ? (uint32_t)__ffsll((long long)um) - 1u : psize;
+        }
+        uint32_t *s = snap + (u64)i * row;
+        for (uint32_t j = lane; j < row; j += 64) s[j] = 0;
+        wave_sync();
+        if (lane == 0) {
+            s[0] = psize;
+            s[1] = cur;
+        }
+        if ((uint32_t)lane < psize) {
+            const u64 e = form ? pk : pool[lane];
+            s[2 + 3 * lane] = (uint32_t)e >> 1;
+            s[3 + 3 * lane] = __float_as_uint(ord2f((uint32_t)(e >> 32)));
+            s[4 + 3 * lane] = (uint32_t)(e & 1ull);
+        }
+        wave_sync();
+    }
+}
+
 template <int MODE, bool IP>
 const void *pick_bipartite(const RoarKernelSel &s, uint32_t dim) {
     const bool wg = s.form == ROAR_FORM_BIPARTITE_WG;
@@ -497,6 +567,13 @@ extern "C" int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uin
         if (e != hipSuccess) return (int)e;
     }
     return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, block_threads(*sel), lds_bytes);
+}
+
+extern "C" int roar_launch_queue_trace(uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids,
+                                       const float *dists, int form, uint32_t *snap, void *stream) {
+    hipLaunchKernelGGL(roar_queue_trace_kernel, dim3(1), dim3(64), (capacity + 4) * 8 + 64, (hipStream_t)stream, capacity, n_ops,
+                       ops, ids, dists, form, snap);
+    return (int)hipGetLastError();
 }
 
 extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream) {

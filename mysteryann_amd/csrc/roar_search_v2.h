@@ -236,52 +236,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of cnt <= 64 candidates when the pool (L_pq <= 64)
-// lives in a register pair of the wave: lane i holds entry i (`pk`; lanes >= psize hold ~0), candidates come from
-// ck[0..cnt).  One pass over the candidates a full pool does not reject (:151-153): a ballot of "pool entry < key"
-// is the key's lower bound (its popcount) -- no binary search; a ballot of "pool entry == key" is the reference's
-// duplicate test (:161-162); the same broadcast key ranks the other candidates and tells every pool entry whether it
-// moves up.  Entry i ends at i + #{candidates landing at or before it}, candidate c at lower_bound(c) + rank(c);
-// the scatter goes through `scratch` (the LDS pool region) and is read back one entry per lane.
-__device__ __forceinline__ void merge_regpool(u64 &pk, uint32_t &psize, const u64 *ck, uint32_t cnt, uint32_t L, u64 *scratch,
-                                              int lane) {
-    const u64 FLAG = 1ull;
-    const u64 ci = (uint32_t)lane < cnt ? ck[lane] : ~0ull;
-    bool valid = (uint32_t)lane < cnt;
-    if (psize == L) valid = valid && ci < (lane_u64(pk, (int)L - 1) & ~FLAG);
-    const u64 todo = __ballot(valid);
-    if (todo == 0) return;
-    const bool inpool = (uint32_t)lane < psize;
-    const u64 pkm = pk & ~FLAG;
-    uint32_t r = 0, shift = 0, lo_mine = 0;
-    u64 dead = 0;  // candidates found to repeat an earlier candidate's key (cannot happen within one adjacency row)
-    for (u64 it = todo; it;) {
-        const int j = __ffsll((long long)it) - 1;
-        it &= it - 1;
-        if ((dead >> j) & 1ull) continue;
-        const u64 kj = lane_u64(ci, j);
-        const u64 below = __ballot(inpool && pkm < kj);
-        if (__ballot(inpool && pkm == kj)) {  // already in the pool
-            if (lane == j) valid = false;
-            continue;
-        }
-        const u64 rep = __ballot(valid && lane > j && ci == kj);
-        dead |= rep;
-        if ((rep >> lane) & 1ull) valid = false;
-        const uint32_t lo_j = (uint32_t)__popcll(below);
-        if (lane == j) lo_mine = lo_j;
-        r += (kj < ci) ? 1u : 0u;
-        shift += (lo_j <= (uint32_t)lane) ? 1u : 0u;
-    }
-    const uint32_t s = (uint32_t)__popcll(__ballot(valid));
-    if (inpool && (uint32_t)lane + shift < L) scratch[(uint32_t)lane + shift] = pk;
-    if (valid && lo_mine + r < L) scratch[lo_mine + r] = ci;
-    psize = (psize + s < L) ? psize + s : L;
-    wave_sync();
-    pk = (uint32_t)lane < psize ? scratch[lane] : ~0ull;
-    wave_sync();
-}
-
 // ctrl words (LDS) of the multi-wave forms: 0 query, 1 candidates of the round trip (NONE = query finished),
 // 2 survivors appended by the waves, 3 pool full, 4-5 reject threshold (register-pool form)
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF>

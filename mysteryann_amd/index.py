@@ -148,6 +148,14 @@ class IndexBipartite:
                                                   parameters.Get("M_sq", int), parameters.Get("M_pjbp", int),
                                                   parameters.Get("L_pjpq", int)))
 
+    def BuildRoarGraphDevice(self, learn_knn, parameters):
+        """BuildRoarGraph from learn->base lists that already live in HBM (int32 CUDA/HIP tensor [n_learn, K], e.g. the
+        output of ExactKnnDevice): roar_build_roargraph_device."""
+        assert learn_knn.is_cuda and learn_knn.is_contiguous() and learn_knn.element_size() == 4
+        capi.check(self._lib.roar_build_roargraph_device(self._h, C.c_void_p(learn_knn.data_ptr()), learn_knn.shape[0],
+                                                         learn_knn.shape[1], parameters.Get("M_sq", int),
+                                                         parameters.Get("M_pjbp", int), parameters.Get("L_pjpq", int)))
+
     def InitVisitedListPool(self, num_threads):
         """index_bipartite.h:133"""
         capi.check(self._lib.roar_init_visited_pool(self._h, int(num_threads)))

@@ -565,6 +565,28 @@ def test_register_pool_boundaries_random_graphs(mode, built_lib):
     idx.close()
 
 
+@pytest.mark.parametrize("form", [0, 1], ids=["ldspool", "regpool"])
+def test_queue_routines_replay_reference_trace(form, golden_dir, built_lib):
+    """A4 on the device: the scripted NeighborPriorityQueue sequence of tests/golden/pq_trace.npz (outputs of the
+    reference's neighbor.h: fill, exact duplicate, equal distance / different id, eviction from a full pool, insert
+    below the cursor, pops until empty, 200 random ops with ties) replayed by the kernels' own insert / select
+    routines -- size, cursor, ids, distances and flags equal after every op."""
+    import ctypes as C
+
+    from mysteryann_amd import capi
+
+    t = np.load(os.path.join(golden_dir, "pq_trace.npz"))
+    cap = int(t["capacity"])
+    ops = np.ascontiguousarray(t["ops"], np.uint8)
+    ids = np.ascontiguousarray(t["ids"], np.uint32)
+    dists = np.ascontiguousarray(t["dists"], np.float32)
+    snap = np.zeros((len(ops), 2 + 3 * cap), np.uint32)
+    capi.check(capi.lib().roar_queue_trace(0, cap, len(ops), ops.ctypes.data_as(C.POINTER(C.c_uint8)), capi.u32p(ids),
+                                           capi.f32p(dists), form, capi.u32p(snap)))
+    bad = np.nonzero((snap != t["snap"]).any(axis=1))[0]
+    assert bad.size == 0, (int(bad[0]), snap[bad[0]].tolist(), t["snap"][bad[0]].tolist())
+
+
 @pytest.mark.parametrize("g", [2, 8])
 def test_one_batch_split_over_g_replicas_equals_single_launch(g, golden_dir, built_lib):
     """BASELINE configs[3] host logic (roar_clone_to_device + roar_search_batch_multi): the index replicated g times

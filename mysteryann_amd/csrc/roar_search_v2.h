@@ -298,6 +298,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         u64 pk = ~0ull;
         uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
         uint32_t a0 = 0, a1 = 0, a2 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
+        uint32_t tgp0 = 0, tgp1 = 0, tgp2 = 0;  // EXACT mode: visited tags of the words in a0..a2, fetched ahead (see below)
+        bool tgp_ok = false;
         const uint32_t *arow = p.adj;
         if (wid == 0) {
             // the entry point is always the first expansion: its adjacency row travels with its base row
@@ -319,6 +321,23 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
             wave_sync();
         }
+
+        // EXACT mode: the visited tags are the one dependent HBM round trip left in front of a hop's row gathers.  Once the
+        // first scoring pass of a hop has come back, the words the NEXT filter will test are known (a0..a2: the rest of a
+        // long row, or the speculatively fetched row of the likely next expansion), and so are their tags: this hop's
+        // marks were stored before that pass was issued and vector memory returns in order.  The loads are issued for
+        // every lane (a lane without a neighbour reads tag 0) and written to no register that is live until then, so
+        // nothing waits for them before the next filter does.  If the next expansion is another row they are dropped.
+        auto prefetch_tags = [&]() {
+            const bool nextrow = wpos > deg;
+            const uint32_t wn = nextrow ? 0u : wpos;
+            const uint32_t dn = nextrow ? uni(a0) : deg;
+            const uint32_t w0 = wn + (uint32_t)lane, w1 = w0 + 64u, w2 = w0 + 128u;
+            tgp0 = __builtin_nontemporal_load(tags + ((w0 >= 1 && w0 <= dn) ? a0 : 0u));
+            tgp1 = __builtin_nontemporal_load(tags + ((w1 >= 1 && w1 <= dn) ? a1 : 0u));
+            tgp2 = __builtin_nontemporal_load(tags + ((w2 >= 1 && w2 <= dn) ? a2 : 0u));
+            tgp_ok = true;
+        };
 
         for (;;) {
             uint32_t m = 0;
@@ -376,6 +395,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             a0 = arow[lane];
                             a1 = arow[64 + lane];
                             a2 = arow[128 + lane];
+                            tgp_ok = false;
                             if (PROF) n_rt++;
                         } else if (PROF) {
                             pf_hit++;
@@ -405,10 +425,11 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     }
                     bool fresh[3];
                     if (MODE == VIS_EXACT) {  // visited_array[nbr] != tag ... = tag  (:2378,2385)
-                        uint32_t tg[3] = {0, 0, 0};
+                        uint32_t tg[3] = {tgp0, tgp1, tgp2};
+                        if (!tgp_ok) {  // (uniform) the words in a0..a2 are not the ones whose tags were fetched ahead
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            if (isn[c]) tg[c] = __builtin_nontemporal_load(tags + nb[c]);
+                            for (int c = 0; c < 3; ++c) tg[c] = __builtin_nontemporal_load(tags + nb[c]);  // (nb = 0 without a neighbour)
+                        }
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             fresh[c] = isn[c] && tg[c] != epoch;
@@ -471,16 +492,22 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         score_rows<IP, NCH, TAIL, R, true, PROF>(p.base, p.ld, p.dim, lq, cid + lo, ck, (m - lo < per) ? m - lo : per,
                                                                  thr, const_cast<uint32_t *>(ctrl + 2), lane, &pprof);
                 }
+                if (MODE == VIS_EXACT && wid == 0) prefetch_tags();
                 lds_barrier();
                 nsurv = ctrl[2];
             } else {
                 if (done) break;
                 wave_sync();
-                if (m) {
-                    u64 thr = ~0ull;
-                    if (psize == L) thr = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
-                    score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid, ck, m, thr, &nsurv, lane, &pprof);
+                u64 thr = ~0ull;
+                if (psize == L) thr = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
+                // first pass (<= 32 rows), then -- EXACT mode -- the visited tags of the NEXT round trip's words, then the rest
+                const uint32_t m1 = m < 32u ? m : 32u;
+                if (m1) score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid, ck, m1, thr, &nsurv, lane, &pprof);
+                if (MODE == VIS_EXACT) {
+                    if (m1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no pass separated this hop's marks from the loads)
+                    prefetch_tags();
                 }
+                if (m > m1) score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid + m1, ck, m - m1, thr, &nsurv, lane, &pprof);
                 wave_sync();
             }
             if (PROF && wid == 0) {

@@ -11,20 +11,23 @@ def newest(pattern):
 
 src, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+if "--no-write-profiles" in sys.argv:  # on the GPU box: summaries next to the raw capture (gpurun_out/), copied into profiles/ later
+    out = src
 os.makedirs(out, exist_ok=True)
+KERNEL = "roar_search_v2_kernel"  # the API launches; the builder's searches run as roar_build_search_v2_kernel
 bench = json.load(open(os.path.join(src, "bench.json")))
 Lchosen = bench["config"]["L_pq"]
 
 
 def search_rows(path):
-    rows = [r for r in csv.DictReader(open(path)) if "roar_search_kernel<1, true" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if KERNEL in r["Kernel_Name"] and "build" not in r["Kernel_Name"]]
     return rows
 
 
 # 1. kernel stats (top 12 rows, names shortened)
 stats = list(csv.DictReader(open(newest(os.path.join(src, "trace/*/*_kernel_stats.csv")))))
 with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --L %d\n" % Lchosen)
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-host-path --L %d\n" % Lchosen)
     f.write("# (whole process: data generation, graph build, ground truth, L sweep is skipped with --L)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in stats[:12]:
@@ -35,19 +38,19 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
 # 2. per-launch durations of the timed steps: the last 5+1+... launches of the IP search kernel at 10 000 queries
 trace = search_rows(newest(os.path.join(src, "trace/*/*_kernel_trace.csv")))
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace]
-timed = durs[-5:]
+timed = durs[-8:]  # the rotating timed loop is the last thing the process launches
 # 3. PMC
 def pmc(name):
     rows = search_rows(newest(os.path.join(src, f"{name}/*/*_counter_collection.csv")))
-    return [float(r["Counter_Value"]) for r in rows][-5:], [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows][-5:]
+    return [float(r["Counter_Value"]) for r in rows][-8:], [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows][-8:]
 fetch, fd = pmc("pmc_fetch")
 write, wd = pmc("pmc_write")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_b = sum(fetch) / len(fetch) * 1024 * 2  # KB -> B, x2 gfx950 correction (calibrated 0.5658 x 2 = 1.1316 = 905 B per 800-B row)
 write_b = sum(write) / len(write) * 1024
 summary = {
-    "command": f"python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --L {Lchosen}",
-    "kernel": "roar_search_kernel<VIS_LDS, IP, NCH=12> (D=200)",
+    "command": f"python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-host-path --L {Lchosen}",
+    "kernel": "roar_search_v2_kernel<VIS_LDS, IP, NCH=12, TAIL, W=1, register pool> (D=200)",
     "timed_launch_durations_ns": timed,
     "avg_launch_ms_rocprof": sum(timed) / len(timed) / 1e6,
     "avg_launch_ms_bench_hip_events": bench["roofline"]["kernel_ms"],
@@ -58,7 +61,7 @@ summary = {
     "traffic_over_algorithmic": (fetch_b + write_b) / alg,
     "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); calibrated on this access pattern: "
                   "distance-only kernel over uniformly random 800-B rows of an 8 GB table reads FETCH_SIZE*1024 = 0.5658 x known bytes "
-                  "(= 7 lines x 128 B / 800 B / 2), see profiles/%s_fetch_calibration.txt" % tag,
+                  "(= 7 lines x 128 B / 800 B / 2), see profiles/r01_fetch_calibration.txt",
     "bench_line": bench,
 }
 json.dump(summary, open(os.path.join(out, f"{tag}_search_kernel_summary.json"), "w"), indent=1)

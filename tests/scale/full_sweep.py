@@ -1,7 +1,9 @@
 """The reference's whole evaluation sweep (run_roargraph_search_test.sh:13, 56 values of L_pq, k = 10)
 on the T2I-10M shape: one CSV row per L_pq in the reference's column order
   L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops
-for the GPU (10 000 queries per launch, kernel time), and for a subset of L_pq the CPU reference-kind
+for the GPU (10 000 queries per launch, kernel time) -- avg_cmps is the REFERENCE algorithm's count (EXACT visited
+mode, untimed second run), kernel_cmps what the timed kernel scored (LDS mode re-scores nodes its tag table forgot),
+roofline_frac = reference-algorithm bytes / kernel time / 8 TB/s -- and for a subset of L_pq the CPU reference-kind
 baseline (16 threads = the box's CPU quota) on the first --cpu-queries queries together with an exact
 comparison of the ids / distances of both sides.  Test infrastructure (runs the oracle)."""
 import argparse, json, os, sys, time
@@ -15,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--cpu-queries", type=int, default=2000)
 ap.add_argument("--out", default="gpurun_out/sweep_t2i10m.csv")
+ap.add_argument("--no-cpu", action="store_true")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
 base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n)
@@ -26,22 +29,30 @@ impl = "ref" if oracle.have_ref() else "port"
 threads = min(oracle.max_threads(impl), bench.effective_cpus())
 hb = base.cpu().numpy(); ep, off, nbrs = idx.GetProjectionGraph(); hq = queries.cpu().numpy()
 cpu_L = {10, 20, 50, 60, 100, 200, 500, 1000, 2000}
-rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
+rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,kernel_cmps,vis_entries,grid,roofline_frac,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
+ap_cpu = not args.no_cpu
 for L in bench.L_LIST:
     for _ in range(2): out = idx.SearchRoarGraphBatchDevice(queries, k, L)
     torch.cuda.synchronize()
     ms = idx.info("last_kernel_ns") / 1e6
+    mode, ve, grid = idx.info("last_visited_mode"), idx.info("last_vis_entries"), idx.info("last_grid")
     rec = bench.recall_at_k(torch, out["ids"], gt, k)
+    idx.set_option("visited_mode", 0)  # the reference algorithm's counters
+    ex = idx.SearchRoarGraphBatchDevice(queries, k, L); torch.cuda.synchronize()
+    idx.set_option("visited_mode", 2)
+    assert bool((ex["ids"] == out["ids"]).all()) and bool((ex["dists"] == out["dists"]).all()) and bool((ex["hops"] == out["hops"]).all())
+    alg = (800.0 * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum() + 8 * ex["hops"].double().sum()).item() + 880.0 * nq
     cpu_qps, same = "", ""
-    if L in cpu_L:
+    if L in cpu_L and ap_cpu:
         m = args.cpu_queries if L <= 200 else max(200, args.cpu_queries // 5)
         oracle.search_batch(hb, off, nbrs, ep, hq[:64], k, L, 1, threads=threads, impl=impl)
         t0 = time.perf_counter(); o = oracle.search_batch(hb, off, nbrs, ep, hq[:m], k, L, 1, threads=threads, impl=impl); dt = time.perf_counter() - t0
         cpu_qps = f"{m / dt:.0f}"
         gi = out["ids"][:m].cpu().numpy().view(np.uint32); gd = out["dists"][:m].cpu().numpy()
         same = f"{float(((gi == o['ids']).all(axis=1) & (gd == o['dists']).all(axis=1)).mean()):.4f}"
-    rows.append(f"{L},{nq / ms * 1e3:.0f},{float(out['cmps'].float().mean()):.1f},{ms / nq:.6f},{rec:.4f},"
-                f"{float(out['hops'].float().mean()):.2f},{'lds' if idx.info('last_visited_mode') == 1 else 'exact'},{cpu_qps},{threads if cpu_qps else ''},{same}")
+    rows.append(f"{L},{nq / ms * 1e3:.0f},{float(ex['cmps'].float().mean()):.1f},{ms / nq:.6f},{rec:.4f},"
+                f"{float(out['hops'].float().mean()):.2f},{'lds' if mode == 1 else 'exact'},{float(out['cmps'].float().mean()):.1f},{ve},{grid},"
+                f"{alg / (ms * 1e-3) / 8e12:.3f},{cpu_qps},{threads if cpu_qps else ''},{same}")
     print(rows[-1], flush=True)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
 open(args.out, "w").write("\n".join(rows) + "\n")

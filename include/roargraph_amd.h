@@ -39,7 +39,7 @@ enum {
  *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
  *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
  *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: LDS for L_pq < 512, EXACT beyond */ };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: LDS for L_pq < 1200 (512 on a graph with a row longer than 170), EXACT beyond */ };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -271,6 +271,11 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
  *                    3 two waves per query; auto picks four waves while the whole batch is resident that way,
  *                    else two waves while it is resident that way, else one
+ *   "pool_form"      0 auto (candidate pool in a register pair of wave 0 for L_pq <= 64, in LDS beyond) | 1 always LDS
+ *   "hub_mode"       0 auto | 1 off | 2 on: for L_pq >= 100 the 65 535 highest-in-degree nodes keep their visited bits
+ *                    in an exact on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs
+ *                    with a row longer than 170 neighbours do without); results do not depend on it
+ *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
  *                    threads while a launch is in flight share the next launch (the reference's harness calls
@@ -278,7 +283,8 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *                    tests/test_search_roargraph.cpp:203-209); 0: one launch per call
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
  *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
- *   "row_stride", "last_grid", "last_lds_bytes", "last_vis_entries", "last_kernel_ns"
+ *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
+ *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */
 int roar_set_option(roar_index *idx, const char *key, int64_t value);

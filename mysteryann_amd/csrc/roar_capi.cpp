@@ -113,6 +113,12 @@ struct roar_index {
     uint32_t *adj = nullptr;
     uint32_t adj_stride = 0, ep = 0, max_deg = 0;
     uint64_t gn = 0, nedges = 0;
+    // hub-annotated copy of the rows for long pools (built on first use): the 65 535 highest-in-degree nodes get a slot
+    // in an exact on-chip visited bitmap; rows list their hub neighbours first and carry the slots behind the ids
+    uint32_t *adj_hub = nullptr;
+    uint32_t hub_stride = 0;
+    int hub_state = 0;   // 0 not built, 1 built, -1 not applicable to this graph (a row longer than 170)
+    int hub_mode = 0;    // option: 0 auto, 1 never, 2 always (when applicable)
     uint64_t graph_hash = 0;  // of the device rows (degree + neighbours in order, per row) and the entry point
     bool graph_hash_valid = false;
     std::vector<uint64_t> h_off;
@@ -196,6 +202,9 @@ int use_device(roar_index *idx) {
 void free_graph(roar_index *idx) {
     if (idx->adj) (void)hipFree(idx->adj);
     idx->adj = nullptr;
+    if (idx->adj_hub) (void)hipFree(idx->adj_hub);
+    idx->adj_hub = nullptr;
+    idx->hub_state = 0;
     idx->h_off.clear();
     idx->h_nbrs.clear();
     idx->gn = idx->nedges = 0;
@@ -330,13 +339,84 @@ int ensure_host_csr(roar_index *idx) {
     return ROAR_OK;
 }
 
+constexpr size_t ADJ_SLACK_WORDS = 256;  // a row read is up to 4 x 64 words from the row's first word
+
+// Hub-annotated adjacency (see RoarSearchParams::adj_hub).  Host pass over the device rows, once per graph: in-degrees,
+// the H = min(65 535, n) nodes with the most in-edges (ties to the smaller id) get bitmap slots 0..H-1, every row is
+// rewritten as [degree | hubs << 16][hub neighbours, in row order][the others, in row order][u16 slot per hub neighbour].
+// Within a hop the scan order cannot change the pool, so listing hubs first changes no result.
+int ensure_hub_rows(roar_index *idx) {
+    if (idx->hub_state != 0) return ROAR_OK;
+    if (!idx->adj || idx->gn == 0) return ROAR_OK;
+    if (idx->max_deg > 170 || idx->gn < 2) {
+        idx->hub_state = -1;
+        return ROAR_OK;
+    }
+    const uint64_t n = idx->gn;
+    const uint32_t S = idx->adj_stride;
+    const uint32_t Sh = round_up(1 + idx->max_deg + (idx->max_deg + 1) / 2, 32);  // <= 256
+    std::vector<uint32_t> rows, hub, indeg, order;
+    std::vector<uint16_t> slot_of;
+    try {
+        rows.resize((size_t)n * S);
+        hub.assign((size_t)n * Sh + ADJ_SLACK_WORDS, 0u);
+        indeg.assign((size_t)n, 0u);
+        order.resize((size_t)n);
+        slot_of.assign((size_t)n, (uint16_t)0xFFFFu);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory for the hub pass");
+    }
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (S * 4));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint64_t cnt = std::min(chunk, n - r0);
+        HIP_TRY(hipMemcpy(rows.data() + r0 * S, idx->adj + r0 * S, (size_t)cnt * S * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint64_t v = 0; v < n; ++v) {
+        const uint32_t *row = rows.data() + v * S;
+        for (uint32_t j = 0; j < row[0]; ++j) indeg[row[1 + j]]++;
+    }
+    const uint32_t H = (uint32_t)std::min<uint64_t>(65535, n);  // slot 0xFFFF means "no slot"
+    for (uint64_t v = 0; v < n; ++v) order[v] = (uint32_t)v;
+    auto more = [&](uint32_t a, uint32_t b) { return indeg[a] != indeg[b] ? indeg[a] > indeg[b] : a < b; };
+    if (H < n) std::nth_element(order.begin(), order.begin() + H, order.end(), more);
+    std::sort(order.begin(), order.begin() + H, more);
+    for (uint32_t s2 = 0; s2 < H; ++s2) slot_of[order[s2]] = (uint16_t)s2;
+    auto build = [&](uint64_t v0, uint64_t v1) {
+        for (uint64_t v = v0; v < v1; ++v) {
+            const uint32_t *row = rows.data() + v * S;
+            uint32_t *o = hub.data() + v * Sh;
+            const uint32_t deg = row[0];
+            uint32_t nh = 0;
+            for (uint32_t j = 0; j < deg; ++j)
+                if (slot_of[row[1 + j]] != 0xFFFFu) o[1 + nh++] = row[1 + j];
+            uint32_t w = nh;
+            for (uint32_t j = 0; j < deg; ++j)
+                if (slot_of[row[1 + j]] == 0xFFFFu) o[1 + w++] = row[1 + j];
+            o[0] = deg | (nh << 16);
+            uint16_t *sl = reinterpret_cast<uint16_t *>(o + 1 + deg);
+            for (uint32_t j = 0; j < nh; ++j) sl[j] = slot_of[o[1 + j]];
+        }
+    };
+    {
+        const unsigned T = n >= (1u << 18) ? 8u : 1u;
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(build, n * t / T, n * (t + 1) / T);
+        build(0, n / T);
+        for (auto &x : th) x.join();
+    }
+    HIP_TRY(hipMalloc((void **)&idx->adj_hub, hub.size() * 4));
+    HIP_TRY(hipMemcpy(idx->adj_hub, hub.data(), hub.size() * 4, hipMemcpyHostToDevice));
+    idx->hub_stride = Sh;
+    idx->hub_state = 1;
+    return ROAR_OK;
+}
+
 struct LaunchPlan {
     RoarSearchParams p;
     RoarKernelSel sel;
     uint32_t grid;
 };
 
-constexpr size_t ADJ_SLACK_WORDS = 256;  // a row read is up to 3 x 64 words from the row's first word
 
 // LDS carve-up and grid for one search launch.
 int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan, bool bipartite = false) {
@@ -365,16 +445,30 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.nq = (uint32_t)nq;
     p.k = k;
     p.L = L;
-    // AUTO: the on-chip tag table while it still leaves 8 waves per CU (L_pq < 512), HBM epoch tags
-    // beyond (measured on T2I-10M: LDS 15.4 / 28.9 / 49.1 ms vs EXACT 19.3 / 33.3 / 50.7 ms at
-    // L_pq = 150 / 300 / 500, but 250 vs 126 ms at L_pq = 1500)
+    // Hub-bitmap form (long pools, L_pq >= 100): the highest-in-degree nodes keep their visited bits in an exact LDS
+    // bitmap, so the tag table / the HBM tags see only the other neighbours (about half of the probes and a fifth of
+    // the revisits on T2I-10M).  T2I-10M, 10 000 queries, best plain form -> best hub form: L_pq = 100 9.96 -> 9.91 ms,
+    // 300 23.99 -> 23.42, 500 37.60 -> 36.85, 700 60.5 -> 49.6, 1 000 85.7 -> 68.5, 1 400 105.7 -> 91.3, 2 000 142.2 ->
+    // 128.6 ms; 1 250 queries: 300 3.74 -> 3.28, 500 5.95 -> 5.19, 1 000 11.3 -> 9.31, 2 000 19.6 -> 17.5 ms
+    // (profiles/r02_hub_forms.txt).
+    bool use_hub = false;
+    if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || L >= 100)) {
+        int e = ensure_hub_rows(idx);
+        if (e) return e;
+        use_hub = idx->hub_state == 1;
+    }
+    // AUTO: the on-chip tag table for short and medium pools, HBM epoch tags beyond.  Without the hub bitmap the table
+    // (8 192 / 16 384 tags) is overrun from L_pq ~ 500 (LDS 49.1 vs EXACT 50.7 ms at 500, 250 vs 126 ms at 1 500); with
+    // it a 4 096-tag table for the non-hub neighbours still beats the HBM tags at L_pq = 1 000 (68.5 vs 74.1 ms) and
+    // draws level at 1 400 (92.7 vs 91.3 ms).
     // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
     const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;
     // (the two-hop walk touches an order of magnitude more distinct nodes per hop: the 8192-tag table forgets
     // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
     // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
+    const uint32_t lds_until = use_hub ? 1200u : 512u;
     const int mode = idx->visited_mode == ROAR_VISITED_AUTO
-                         ? ((L < 512 && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
+                         ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                          : idx->visited_mode;
     // bipartite, AUTO: eight waves per query while the pool is short (work per query is far too uneven for one
     // wave each: T2I-10M, 10 000 queries, 14.0 / 20.0 / 32.8 / 44.9 / 68.2 ms at L_pq = 10 / 20 / 50 / 100 / 200 against
@@ -392,8 +486,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // 10.49 / 9.97 / 14.26 ms, 300: 26.79 / 24.05 / 35.45 ms, 500: 43.32 / 37.74 / 55.95 ms (cmps 36.5 k / 29.9 k
         // against the reference's 27.0 k); 2 500 queries: 100: 2.81 / 2.87, 300: 7.21 / 7.04, 500: 11.61 / 11.02 ms;
         // 1 250 queries: the small table wins everywhere (profiles/r02_kernel_forms.txt).  L_pq = 60: 6.09 vs 7.26 ms.
+        // With the hub bitmap the table holds the non-hub neighbours only: 8 192 tags below L_pq = 500, 4 096 beyond (LDS is
+        // then better spent on resident waves: 1 250 queries at L_pq = 500, 5.19 ms with 4 096 tags, 6.90 ms with 8 192).
         uint32_t want = 8192u;
-        if ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000)) want = 16384u;
+        if (use_hub) want = L < 500 ? 8192u : 4096u;
+        else if ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000)) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
@@ -416,6 +513,14 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     off += 2 * entries;
     p.off_ctrl = off;
     off += bp_wg ? 64 : 32;
+    if (use_hub) {  // row buffer + bitmap of the hub form
+        p.off_rowbuf = off;
+        off += 1024;
+        p.off_hbits = off;
+        off += 8192;
+        p.adj_hub = idx->adj_hub;
+        p.hub_stride = idx->hub_stride;
+    }
     if (bipartite) {
         p.off_bp = off;
         off += 768;
@@ -434,6 +539,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     sel.waves = 1;
     sel.regpool = (L <= 64 && idx->pool_form == 0) ? 1 : 0;
     sel.prof = idx->profile ? 1 : 0;
+    sel.hub = use_hub ? 1 : 0;
     if (sel.prof && !(idx->ip && idx->dim_pad == 200))
         return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product shape only");
     int occ = 0;
@@ -445,13 +551,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     bool picked = false;
     if (bipartite) {
         sel.form = bp_wg ? ROAR_FORM_BIPARTITE_WG : ROAR_FORM_BIPARTITE;
-        sel.prof = sel.regpool = 0;
+        sel.prof = sel.regpool = sel.hub = 0;
         int e = occupancy(&occ);
         if (e) return e;
         picked = true;
     } else if (idx->building && mode == ROAR_VISITED_LDS) {
         sel.form = ROAR_FORM_BUILDER;
-        sel.prof = 0;
+        sel.prof = sel.hub = 0;
         int e = occupancy(&occ);
         if (e) return e;
         picked = true;
@@ -462,6 +568,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
             if (idx->search_kernel == 2 && w != 4) continue;
             if (idx->search_kernel == 3 && w != 2) continue;
             sel.waves = w;
+            if (sel.prof && sel.hub) continue;  // (the instrumented hub form exists for one wave per query)
             int occ_mw = 0;
             int e = occupancy(&occ_mw);
             if (e) return e;
@@ -2022,6 +2129,9 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
         idx->search_kernel = (int)value;
+    } else if (k == "hub_mode") {
+        if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
+        idx->hub_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");
         idx->pool_form = (int)value;
@@ -2059,6 +2169,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
         *value = idx->last_sel.form == ROAR_FORM_BIPARTITE_WG ? 8
                  : idx->last_sel.form == ROAR_FORM_SEARCH ? idx->last_sel.waves : 1;
     else if (k == "last_register_pool") *value = idx->last_sel.regpool;
+    else if (k == "last_hub_bitmap") *value = idx->last_sel.hub;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

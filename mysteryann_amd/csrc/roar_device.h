@@ -46,6 +46,11 @@ struct RoarSearchParams {
     // eight-waves-per-query form: one u32[tag_stride32] epoch list per resident workgroup (test-and-set)
     uint32_t *tags32;
     uint64_t tag_stride32;
+    // hub-annotated copy of the adjacency (long pools): rows of hub_stride words, word 0 = degree | hubs << 16, hub
+    // neighbours first, one u16 bitmap slot per hub neighbour behind the ids; LDS: 256-word row buffer + 8 KB bitmap
+    const uint32_t *adj_hub;
+    uint32_t hub_stride;
+    uint32_t off_rowbuf, off_hbits;
     // per-query phase timers of the instrumented kernels (u64[nq][8]: total, select, adjacency, filter, score, merge
     // shader-clock cycles of wave 0, speculative adjacency fetches that were used, adjacency round trips paid); may be null
     unsigned long long *prof;
@@ -60,6 +65,7 @@ struct RoarKernelSel {
     int waves;         // SEARCH: waves per query (1, 2, 4)
     int regpool;       // SEARCH / BUILDER: candidate pool in a register pair of wave 0 (L_pq <= 64) instead of LDS
     int prof;          // SEARCH: instrumented instantiation (phase timers; Text-to-Image shape only)
+    int hub;           // SEARCH: hub-bitmap form (LDS pool only)
 };
 
 struct RoarDistParams {

@@ -10,7 +10,9 @@
 //     unexpanded pool entry as it stands before the hop's merges) is already in flight; it is used if the merges
 //     leave that entry in front, dropped otherwise (results cannot depend on it);
 //   * the visited filter runs over the whole row at once (LDS mode: three compare-and-swaps per lane in flight;
-//     EXACT mode: the tag loads of all three chunks in flight), the survivors of the whole hop are packed, scored
+//     EXACT mode: the tag loads of all three chunks in flight; long pools: the highest-in-degree nodes have their
+//     visited bits in an exact on-chip bitmap, named by slot in a hub-annotated copy of the adjacency, and only the
+//     other neighbours go to the tag table / the HBM tags), the survivors of the whole hop are packed, scored
 //     R x 16 rows per pass -- every load of a pass, the 8-float tail of a D = 200 row included, issued before the
 //     first FMA -- and keys a full pool would reject are dropped before the merge;
 //   * for L_pq <= 64 the candidate pool lives in ONE VGPR PAIR of wave 0 (lane i = i-th entry): closest_unexpanded is
@@ -238,7 +240,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ctrl words (LDS) of the multi-wave forms: 0 query, 1 candidates of the round trip (NONE = query finished),
 // 2 survivors appended by the waves, 3 pool full, 4-5 reject threshold (register-pool form)
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     extern __shared__ __align__(16) unsigned char smem[];
@@ -249,6 +251,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     float *lq = reinterpret_cast<float *>(smem + p.off_q);
     uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
     volatile uint32_t *ctrl = reinterpret_cast<volatile uint32_t *>(smem + p.off_ctrl);
+    // HUB form (long pools): rows come from the hub-annotated adjacency -- word 0 = degree | hubs << 16, the row's hub
+    // neighbours first, then the others, then one u16 bitmap slot per hub neighbour -- in one round trip of 4 x 64 words
+    // (such a graph has no row longer than 170); hub neighbours are tested and marked in an exact LDS bitmap (hbits,
+    // 65 536 bits), only the others go to the tag table / the HBM tags.
+    uint32_t *rowbuf = reinterpret_cast<uint32_t *>(smem + p.off_rowbuf);
+    uint32_t *hbits = reinterpret_cast<uint32_t *>(smem + p.off_hbits);
+    const uint32_t *const ADJ = HUB ? p.adj_hub : p.adj;
+    const uint32_t AS = HUB ? p.hub_stride : p.adj_stride;
     const uint32_t L = p.L;
     const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -282,7 +292,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         if (MODE == VIS_LDS) {  // fresh visited table
             const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
             for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
-        } else {  // VisitedList::reset (visited_list_pool.h:20-26) with a u8 epoch
+        }
+        if (HUB)
+            for (uint32_t i = threadIdx.x; i < 512u; i += 64 * W) reinterpret_cast<uint4 *>(hbits)[i] = make_uint4(0, 0, 0, 0);
+        if (MODE == VIS_EXACT) {  // VisitedList::reset (visited_list_pool.h:20-26) with a u8 epoch
             epoch++;
             if (epoch == 256u) {
                 for (u64 i = (u64)threadIdx.x * 16; i < p.tag_stride; i += 1024 * W)
@@ -297,16 +310,16 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         // cursor `cur` = index of the closest unexpanded entry.
         u64 pk = ~0ull;
         uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
-        uint32_t a0 = 0, a1 = 0, a2 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
-        uint32_t tgp0 = 0, tgp1 = 0, tgp2 = 0;  // EXACT mode: visited tags of the words in a0..a2, fetched ahead (see below)
-        bool tgp_ok = false;
-        const uint32_t *arow = p.adj;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
+        uint32_t nhub = 0;  // HUB: hub neighbours of the current row (they come first)
+        const uint32_t *arow = ADJ;
         if (wid == 0) {
             // the entry point is always the first expansion: its adjacency row travels with its base row
-            arow = p.adj + (u64)p.ep * p.adj_stride;
+            arow = ADJ + (u64)p.ep * AS;
             a0 = arow[lane];
             a1 = arow[64 + lane];
             a2 = arow[128 + lane];
+            if (HUB) a3 = arow[192 + lane];
             pf = p.ep;
             // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
             if (lane == 0) cid[0] = p.ep;
@@ -321,23 +334,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
             wave_sync();
         }
-
-        // EXACT mode: the visited tags are the one dependent HBM round trip left in front of a hop's row gathers.  Once the
-        // first scoring pass of a hop has come back, the words the NEXT filter will test are known (a0..a2: the rest of a
-        // long row, or the speculatively fetched row of the likely next expansion), and so are their tags: this hop's
-        // marks were stored before that pass was issued and vector memory returns in order.  The loads are issued for
-        // every lane (a lane without a neighbour reads tag 0) and written to no register that is live until then, so
-        // nothing waits for them before the next filter does.  If the next expansion is another row they are dropped.
-        auto prefetch_tags = [&]() {
-            const bool nextrow = wpos > deg;
-            const uint32_t wn = nextrow ? 0u : wpos;
-            const uint32_t dn = nextrow ? uni(a0) : deg;
-            const uint32_t w0 = wn + (uint32_t)lane, w1 = w0 + 64u, w2 = w0 + 128u;
-            tgp0 = __builtin_nontemporal_load(tags + ((w0 >= 1 && w0 <= dn) ? a0 : 0u));
-            tgp1 = __builtin_nontemporal_load(tags + ((w1 >= 1 && w1 <= dn) ? a1 : 0u));
-            tgp2 = __builtin_nontemporal_load(tags + ((w2 >= 1 && w2 <= dn) ? a2 : 0u));
-            tgp_ok = true;
-        };
 
         for (;;) {
             uint32_t m = 0;
@@ -389,18 +385,22 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             c0 = c1;
                         }
                         // adjacency row: word 0 = degree, word w (>= 1) = neighbour w - 1
-                        arow = p.adj + (u64)v * p.adj_stride;
+                        arow = ADJ + (u64)v * AS;
                         vcur = v;
                         if (v != pf) {  // the speculative fetch went to another row: pay the round trip now
                             a0 = arow[lane];
                             a1 = arow[64 + lane];
                             a2 = arow[128 + lane];
-                            tgp_ok = false;
+                            if (HUB) a3 = arow[192 + lane];
                             if (PROF) n_rt++;
                         } else if (PROF) {
                             pf_hit++;
                         }
                         deg = uni(a0);
+                        if (HUB) {
+                            nhub = deg >> 16;
+                            deg &= 0xFFFFu;
+                        }
                         scanned += deg;
                         wpos = 0;
                     }
@@ -423,13 +423,29 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         t_adj += c1 - c0;
                         c0 = c1;
                     }
+                    bool hfresh[3] = {false, false, false};
+                    if (HUB) {
+                        // the slots sit behind the ids, two per word: pass the four registers through LDS to index them
+                        rowbuf[lane] = a0, rowbuf[64 + lane] = a1, rowbuf[128 + lane] = a2, rowbuf[192 + lane] = a3;
+                        wave_sync();
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const uint32_t j = 64u * (uint32_t)c + (uint32_t)lane - 1u;  // neighbour index of word w
+                            const bool hub = isn[c] && j < nhub;
+                            if (hub) {
+                                const uint32_t slot = (rowbuf[1 + deg + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                                const uint32_t bit = 1u << (slot & 31);
+                                hfresh[c] = (atomicOr(&hbits[slot >> 5], bit) & bit) == 0;
+                                isn[c] = false;  // settled: the filters below see only the other neighbours
+                            }
+                        }
+                        wave_sync();
+                    }
                     bool fresh[3];
                     if (MODE == VIS_EXACT) {  // visited_array[nbr] != tag ... = tag  (:2378,2385)
-                        uint32_t tg[3] = {tgp0, tgp1, tgp2};
-                        if (!tgp_ok) {  // (uniform) the words in a0..a2 are not the ones whose tags were fetched ahead
+                        uint32_t tg[3];  // the three loads are issued together (a lane without a neighbour reads tag 0)
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) tg[c] = __builtin_nontemporal_load(tags + nb[c]);  // (nb = 0 without a neighbour)
-                        }
+                        for (int c = 0; c < 3; ++c) tg[c] = __builtin_nontemporal_load(tags + (isn[c] ? nb[c] : 0u));
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             fresh[c] = isn[c] && tg[c] != epoch;
@@ -440,11 +456,12 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const u64 fm = __ballot(fresh[c]);
-                        if (fresh[c]) cid[m + lanes_below(fm)] = nb[c];
+                        const bool f = fresh[c] | hfresh[c];
+                        const u64 fm = __ballot(f);
+                        if (f) cid[m + lanes_below(fm)] = nb[c];
                         m += (uint32_t)__popcll(fm);
                     }
-                    wpos += 192u;
+                    wpos += HUB ? 256u : 192u;
                     cmps += m;  // ++cmps per scored neighbour, :2397
                     // Next adjacency words, in flight while this round trip's rows are scored: the rest of this row
                     // if it is longer, else the row of the closest unexpanded entry as the pool stands now -- if this
@@ -454,11 +471,12 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         if (wpos > deg) {
                             if constexpr (RP) pf = (nextv != NONE) ? nextv : vcur;  // (nothing left: any valid row)
                             else pf = (cur < psize) ? (uint32_t)pool[cur] >> 1 : vcur;
-                            nrow = p.adj + (u64)pf * p.adj_stride;
+                            nrow = ADJ + (u64)pf * AS;
                         }
                         a0 = nrow[lane];
                         a1 = nrow[64 + lane];
                         a2 = nrow[128 + lane];
+                        if (HUB) a3 = nrow[192 + lane];
                     }
                     if (PROF) {
                         c1 = (long long)__builtin_readcyclecounter();
@@ -492,7 +510,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         score_rows<IP, NCH, TAIL, R, true, PROF>(p.base, p.ld, p.dim, lq, cid + lo, ck, (m - lo < per) ? m - lo : per,
                                                                  thr, const_cast<uint32_t *>(ctrl + 2), lane, &pprof);
                 }
-                if (MODE == VIS_EXACT && wid == 0) prefetch_tags();
                 lds_barrier();
                 nsurv = ctrl[2];
             } else {
@@ -500,14 +517,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 wave_sync();
                 u64 thr = ~0ull;
                 if (psize == L) thr = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
-                // first pass (<= 32 rows), then -- EXACT mode -- the visited tags of the NEXT round trip's words, then the rest
-                const uint32_t m1 = m < 32u ? m : 32u;
-                if (m1) score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid, ck, m1, thr, &nsurv, lane, &pprof);
-                if (MODE == VIS_EXACT) {
-                    if (m1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no pass separated this hop's marks from the loads)
-                    prefetch_tags();
-                }
-                if (m > m1) score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid + m1, ck, m - m1, thr, &nsurv, lane, &pprof);
+                if (m) score_rows<IP, NCH, TAIL, R, false, PROF>(p.base, p.ld, p.dim, lq, cid, ck, m, thr, &nsurv, lane, &pprof);
                 wave_sync();
             }
             if (PROF && wid == 0) {
@@ -570,10 +580,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
 // Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of
 // a scoring pass for an occupancy the LDS footprint does not allow anyway).
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -581,7 +591,7 @@ roar_search_v2_kernel(const RoarSearchParams p) {
 template <bool IP, int NCH, bool TAIL, bool RP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 roar_build_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<VIS_LDS, IP, NCH, TAIL, 1, RP, false>(p);
+    search_v2<VIS_LDS, IP, NCH, TAIL, 1, RP, false, false>(p);
 }
 
 template <int MODE, bool IP, int NCH, bool TAIL>
@@ -593,6 +603,16 @@ const void *pick_form(const RoarKernelSel &s) {
                       : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
         else
             return nullptr;
+    }
+    if (s.hub) {  // long pools: LDS pool, hub bitmap
+        if (rp) return nullptr;
+        if (s.prof) {
+            if constexpr (IP && NCH == 12) return s.waves == 1 ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true, true> : nullptr;
+            else return nullptr;
+        }
+        if (s.waves == 4) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, false, false, true>;
+        if (s.waves == 2) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, false, false, true>;
+        return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, true>;
     }
     if (s.prof) {  // instrumented instantiations exist for the Text-to-Image shape only
         if constexpr (IP && NCH == 12) {

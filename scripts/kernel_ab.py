@@ -12,14 +12,24 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--out", default="gpurun_out/kernel_ab.txt")
 ap.add_argument("--Ls", type=int, nargs="+", default=[30, 100, 300, 500, 1000, 2000])
 ap.add_argument("--nqs", type=int, nargs="+", default=[256, 1250, 2500, 10000])
+ap.add_argument("--builder", default="bootstrap", choices=["bootstrap", "reference"])
+ap.add_argument("--ref-learn", type=int, default=2_000_000)
+ap.add_argument("--prof-Ls", type=int, nargs="*", default=None)
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
 lines = []
 def say(s):
     print(s, flush=True); lines.append(s)
-base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n)
+base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n if args.builder == "bootstrap" else args.ref_learn)
 idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn
+t0 = time.time()
+if args.builder == "bootstrap":
+    idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128)
+else:
+    lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
+    pp = mi.Parameters(); pp.Set("M_sq", 100); pp.Set("M_pjbp", 35); pp.Set("L_pjpq", 500)
+    idx.BuildRoarGraphDevice(lists, pp); del lists
+torch.cuda.synchronize(); del learn
 say(f"# n={n} index built in {time.time() - t0:.1f}s avg degree {idx.info('nedges') / n:.1f} max {idx.info('max_degree')}")
 
 def run(nq, L, kern, vis, reps=3, ve=0, pool=0):
@@ -53,7 +63,8 @@ for L in args.Ls:
 
 names = ["select", "adj", "filter", "score", "merge"]
 idx.set_option("profile_phases", 1)
-for L, vis in ((30, 1), (100, 1), (500, 1), (500, 0), (2000, 0)):
+prof_cfg = ((30, 1), (100, 1), (500, 1), (500, 0), (2000, 0)) if args.prof_Ls is None else tuple((L, 1 if L < 512 else 0) for L in args.prof_Ls)
+for L, vis in prof_cfg:
     for nq in (1, 1250, 10000):
         out, ms = run(nq, L, 1, vis, reps=2)
         pr = idx.LastProfile(nq).astype(np.float64)

@@ -565,6 +565,47 @@ def test_register_pool_boundaries_random_graphs(mode, built_lib):
     idx.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
+def test_hub_bitmap_form_matches_goldens_and_oracle(mode, golden_dir, built_lib):
+    """Long-pool form: the highest-in-degree nodes keep their visited bits in an exact on-chip bitmap (a hub-annotated
+    copy of the adjacency lists them first, with their slots).  Goldens (2 000 points: every node is a hub) in all wave
+    forms, and a 70 000-node random graph where only some neighbours are hubs: ids, distances, hops -- and in EXACT mode
+    cmps -- equal the reference's / the oracle's, hub form on or off."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    for case in ("ip_200", "l2_128"):
+        exp = np.load(os.path.join(golden_dir, case + ".expected.npz"))
+        idx, q = _index(case, golden_dir, mode)
+        idx.set_option("hub_mode", 2)
+        for kernel in (1, 3, 2):
+            idx.set_option("search_kernel", kernel)
+            for L in (100, 200):
+                r = idx.SearchRoarGraphBatch(q, K, L)
+                assert idx.info("last_hub_bitmap") == 1
+                for key in ("ids", "dists", "hops", "scanned", "cmps"):
+                    assert np.array_equal(r[key], exp[f"{key}_{L}"]), (case, kernel, L, key)
+        idx.close()
+    n, d, nq = 70_000, 16, 32
+    base, q, off, nbrs = _random_case(n, d, nq, 1, seed=5, maxdeg=60)
+    nbrs[: len(nbrs) // 2] = nbrs[: len(nbrs) // 2] % 3000  # a few thousand nodes collect half of the in-edges
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(11, off, nbrs)
+    idx.set_option("visited_mode", mode)
+    for L in (70, 130, 600):
+        o = oracle.search_batch(base, off, nbrs, 11, q, K, L, 1)
+        for hub in (2, 1):
+            idx.set_option("hub_mode", hub)
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            assert idx.info("last_hub_bitmap") == (1 if hub == 2 else 0)
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"]), (L, hub)
+            assert np.array_equal(r["hops"], o["hops"]), (L, hub)
+            if mode == 0:
+                assert np.array_equal(r["cmps"], o["cmps"]), (L, hub)
+    idx.close()
+
+
 @pytest.mark.parametrize("form", [0, 1], ids=["ldspool", "regpool"])
 def test_queue_routines_replay_reference_trace(form, golden_dir, built_lib):
     """A4 on the device: the scripted NeighborPriorityQueue sequence of tests/golden/pq_trace.npz (outputs of the

@@ -187,12 +187,17 @@ def test_forgetful_visited_table_keeps_results(built_lib):
     idx.SetProjectionGraph(0, off, nbrs)
     idx.set_option("visited_mode", 1)
     idx.set_option("vis_entries", 64)
+    idx.set_option("hub_mode", 1)  # (with the hub bitmap every node of a 20 000-point graph has an exact visited bit)
     o = oracle.search_batch(base, off, nbrs, 0, q, K, 150, 0)
     r = idx.SearchRoarGraphBatch(q, K, 150)
     assert np.array_equal(r["ids"], o["ids"])
     assert np.array_equal(r["dists"], o["dists"])
     assert np.array_equal(r["hops"], o["hops"])
     assert (r["cmps"] >= o["cmps"]).all() and (r["cmps"] > o["cmps"]).any()
+    idx.set_option("hub_mode", 0)  # ... and then nothing is ever forgotten, however small the table
+    r = idx.SearchRoarGraphBatch(q, K, 150)
+    assert idx.info("last_hub_bitmap") == 1
+    assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["cmps"], o["cmps"])
 
 
 def test_exact_mode_epoch_wrap(built_lib):
@@ -461,8 +466,9 @@ def test_exact_knn_query_block_larger_than_one_launch(built_lib):
 
 
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
-    """Default policy: on-chip tag table below L_pq = 512, HBM epoch tags from there on; both give the
-    reference's results."""
+    """Default policy: on-chip tag table below L_pq = 1200 (the hub bitmap carries the busiest nodes from L_pq = 100),
+    HBM epoch tags from there on; without the hub form (option, or a graph with a row longer than 170) the switch is at
+    512.  All give the reference's results."""
     import oracle
     from mysteryann_amd import index as mi
 
@@ -472,12 +478,15 @@ def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
     idx.SetBaseData(base)
     idx.SetProjectionGraph(9, off, nbrs)
     assert idx.info("visited_mode") == 2
-    for L, want_mode in ((50, 1), (511, 1), (512, 0), (900, 0)):
-        r = idx.SearchRoarGraphBatch(q, K, L)
-        assert idx.info("last_visited_mode") == want_mode
-        o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
-        assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
-        assert np.array_equal(r["hops"], o["hops"])
+    for hub_mode, cases in ((0, ((50, 1, 0), (99, 1, 0), (100, 1, 1), (1199, 1, 1), (1200, 0, 1), (1500, 0, 1))),
+                            (1, ((50, 1, 0), (511, 1, 0), (512, 0, 0), (900, 0, 0)))):
+        idx.set_option("hub_mode", hub_mode)
+        for L, want_mode, want_hub in cases:
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            assert idx.info("last_visited_mode") == want_mode and idx.info("last_hub_bitmap") == want_hub, (hub_mode, L)
+            o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
+            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
+            assert np.array_equal(r["hops"], o["hops"])
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
@@ -709,6 +718,45 @@ def test_pinned_query_block_is_read_in_place(golden_dir, built_lib):
                                          capi.f32p(dists), None, capi.u32p(hops), None))
         assert np.array_equal(ids, exp["ids_50"]) and np.array_equal(dists, exp["dists_50"]) and np.array_equal(hops, exp["hops_50"])
         lib.roar_host_free(ptr)
+    idx.close()
+
+
+def test_reference_builder_tracks_restated_reference_builder_at_200k(golden_dir, built_lib):
+    """SURVEY 8(f) #1 at a size where graph quality shows.  tests/golden/builder_yardstick_200000.json holds the degree
+    statistics and the recall@10 / distance-evaluation curve of the CPU restatement of the reference's BuildRoarGraph
+    (oracle/roar_builder_oracle.c, 23 minutes single-threaded; tests/scale/builder_yardstick.py) on a seeded 200 000-point
+    T2I-shape set with the canonical parameters.  roar_build_roargraph_device on the same data and the same exact lists
+    must track it: entry point equal, average degree within 3 %, longest row equal, recall within 0.005 and distance
+    evaluations within 5 % at L_pq = 20 / 50 / 100 (the reference builder itself is order-dependent, so bytes cannot be
+    compared)."""
+    import json
+
+    import torch
+
+    from mysteryann_amd import index as mi, synth
+
+    Y = json.load(open(os.path.join(golden_dir, "builder_yardstick_200000.json")))
+    n, nq = Y["n"], Y["nq"]
+    base, q, learn = synth.t2i_numpy(n, nq, 200, seed=Y["seed"], n_learn=Y["n_learn"])
+    idx = mi.IndexBipartite(200, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    lists, _ = idx.ExactKnnDevice(torch.from_numpy(learn).cuda(), 100, want_dists=False)
+    p = mi.Parameters()
+    p.Set("M_sq", Y["M_sq"]), p.Set("M_pjbp", Y["M_pjbp"]), p.Set("L_pjpq", Y["L_pjpq"])
+    idx.BuildRoarGraphDevice(lists, p)
+    assert idx.info("ep") == Y["ep"]
+    avg = idx.info("nedges") / n
+    assert abs(avg - Y["avg_degree"]) <= 0.03 * Y["avg_degree"], (avg, Y["avg_degree"])
+    assert idx.info("max_degree") == Y["max_degree"]
+    qd = torch.from_numpy(q).cuda()
+    gt = idx.ExactKnnDevice(qd, 10, want_dists=False)[0].cpu().numpy().view(np.uint32)
+    idx.set_option("visited_mode", 0)  # the reference algorithm's distance-evaluation count
+    for L in (20, 50, 100):
+        r = idx.SearchRoarGraphBatch(q, 10, L)
+        rec = mi.ComputeRecall(r["ids"], gt, 10)
+        want = Y["curve"][str(L)]
+        assert abs(rec - want["recall_at_10"]) <= 0.005, (L, rec, want)
+        assert abs(r["cmps"].mean() - want["avg_cmps"]) <= 0.05 * want["avg_cmps"], (L, r["cmps"].mean(), want)
     idx.close()
 
 

@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--ref-learn", type=int, default=0,
                     help="--builder reference: training queries whose exact top-100 lists are computed (0 = n / 5; T2I-10M: "
                          "1 M / 2 M / 4 M lists -> recall 0.903 / 0.908 / 0.911 at L_pq 55, 50 / 100 / 200 s of f32 MFMA)")
+    ap.add_argument("--graph-cache", default="",
+                    help="index file: loaded if it exists (LoadProjectionGraph), else written after the build -- lets the "
+                         "profiling passes of one box session (scripts/profile_r2.sh) skip the four-minute build; the graph "
+                         "hash in the JSON says it is the same graph")
     ap.add_argument("--max-L", type=int, default=2000)
     ap.add_argument("--exact-knn", type=int, default=0,
                     help="exact learn->base kNN lists (MFMA brute force) for the first N training queries")
@@ -195,7 +199,11 @@ def main():
     idx.SetBaseData(base)
     learn_knn = None
     t0 = time.time()
-    if args.builder == "reference":
+    cached = bool(args.graph_cache) and os.path.exists(args.graph_cache)
+    if cached:
+        idx.LoadProjectionGraph(args.graph_cache)
+        index_desc = f"loaded from {os.path.basename(args.graph_cache)} (written by an earlier run of this command on this box)"
+    elif args.builder == "reference":
         lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
         torch.cuda.synchronize()
         knn_s = time.time() - t0
@@ -225,7 +233,9 @@ def main():
                       f"L={args.build_supplyL}; trim {args.build_trim[0]}/{args.build_trim[1]}")
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    graph_hash = idx.info("graph_hash")
+    if args.graph_cache and not cached and rank == 0:
+        idx.SaveProjectionGraph(args.graph_cache)
+    graph_hash = idx.info("graph_hash") & (2 ** 64 - 1)
     log(f"[rank {rank}] graph ({args.builder}): {build_s:.1f}s, avg degree {idx.info('nedges') / args.n:.1f}, "
         f"max degree {idx.info('max_degree')}, ep {idx.info('ep')}, adjacency stride {idx.info('adj_stride')} words, "
         f"hash {graph_hash:016x}")

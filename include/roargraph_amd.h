@@ -39,7 +39,7 @@ enum {
  *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
  *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
  *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: LDS for L_pq < 1200 (512 on a graph with a row longer than 170), EXACT beyond */ };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the on-chip table up to L_pq ~ 1200-1500 (the switch point depends on the graph's density and on the hub form, csrc/roar_capi.cpp plan_search), HBM tags beyond */ };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -272,9 +272,10 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *                    3 two waves per query; auto picks four waves while the whole batch is resident that way,
  *                    else two waves while it is resident that way, else one
  *   "pool_form"      0 auto (candidate pool in a register pair of wave 0 for L_pq <= 64, in LDS beyond) | 1 always LDS
- *   "hub_mode"       0 auto | 1 off | 2 on: for L_pq >= 100 the 65 535 highest-in-degree nodes keep their visited bits
- *                    in an exact on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs
- *                    with a row longer than 170 neighbours do without); results do not depend on it
+ *   "hub_mode"       0 auto | 1 off | 2 on: the 65 535 highest-in-degree nodes keep their visited bits in an exact
+ *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row
+ *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on graphs of average degree >= 24;
+ *                    results do not depend on it
  *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host

@@ -445,28 +445,34 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.nq = (uint32_t)nq;
     p.k = k;
     p.L = L;
-    // Hub-bitmap form (long pools, L_pq >= 100): the highest-in-degree nodes keep their visited bits in an exact LDS
-    // bitmap, so the tag table / the HBM tags see only the other neighbours (about half of the probes and a fifth of
-    // the revisits on T2I-10M).  T2I-10M, 10 000 queries, best plain form -> best hub form: L_pq = 100 9.96 -> 9.91 ms,
-    // 300 23.99 -> 23.42, 500 37.60 -> 36.85, 700 60.5 -> 49.6, 1 000 85.7 -> 68.5, 1 400 105.7 -> 91.3, 2 000 142.2 ->
-    // 128.6 ms; 1 250 queries: 300 3.74 -> 3.28, 500 5.95 -> 5.19, 1 000 11.3 -> 9.31, 2 000 19.6 -> 17.5 ms
-    // (profiles/r02_hub_forms.txt).
+    // Long pools.  What pays depends on how many rows a hop gathers: a dense graph (the bootstrap builder's: average
+    // degree 33, hub rows of 128, ~97 rows scored per hop) saturates HBM with 4-5 waves per CU and has LDS to spare; a
+    // sparse one (the reference-shaped builder's: average degree 16, ~49 rows per hop) needs its 8 waves per CU.
+    //   dense graph, L_pq >= 100: hub-bitmap form -- the 65 535 highest-in-degree nodes keep their visited bits in an
+    //     exact LDS bitmap, the tag table / the HBM tags see only the other neighbours.  T2I-10M bootstrap graph,
+    //     10 000 queries, best plain form -> best hub form: L_pq = 100 9.96 -> 9.91 ms, 300 23.99 -> 23.42, 500 37.60 ->
+    //     36.85, 700 60.5 -> 49.6, 1 000 85.7 -> 68.5, 1 400 105.7 -> 91.3, 2 000 142.2 -> 128.6 ms; 1 250 queries:
+    //     300 3.74 -> 3.28, 500 5.95 -> 5.19, 1 000 11.3 -> 9.31, 2 000 19.6 -> 17.5 ms.  The on-chip table (4 096 tags
+    //     from L_pq = 500) then beats the HBM tags up to L_pq ~ 1 200 (1 000: 68.5 vs 74.1 ms; 1 400: 92.7 vs 91.3 ms).
+    //   sparse graph: the plain form with 8 192 tags up to L_pq = 1 500, HBM tags beyond.  T2I-10M reference-shaped
+    //     graph, 10 000 queries, 8 192 tags / 4 096 tags + hub bitmap / 16 384 tags / HBM tags: L_pq = 100 6.17 / 6.14 /
+    //     6.63 / 7.82 ms, 500 26.0 / 26.1 / 28.4 / 33.8, 1 000 55.0 / 55.6 / 74.8 / 63.9, 1 400 78.3 / 79.0 / 108.9 / 85.7,
+    //     2 000 131.0 / 134.7 / 162.9 / 116.0 ms (profiles/r02_hub_forms*.txt).
+    const bool dense = idx->gn && (double)idx->nedges / (double)idx->gn >= 24.0;
     bool use_hub = false;
-    if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || L >= 100)) {
+    if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
         int e = ensure_hub_rows(idx);
         if (e) return e;
         use_hub = idx->hub_state == 1;
     }
-    // AUTO: the on-chip tag table for short and medium pools, HBM epoch tags beyond.  Without the hub bitmap the table
-    // (8 192 / 16 384 tags) is overrun from L_pq ~ 500 (LDS 49.1 vs EXACT 50.7 ms at 500, 250 vs 126 ms at 1 500); with
-    // it a 4 096-tag table for the non-hub neighbours still beats the HBM tags at L_pq = 1 000 (68.5 vs 74.1 ms) and
-    // draws level at 1 400 (92.7 vs 91.3 ms).
+    // AUTO: the on-chip tag table for short and medium pools, HBM epoch tags beyond (without the hub bitmap a dense
+    // graph overruns the table from L_pq ~ 500: LDS 49.1 vs EXACT 50.7 ms at 500, 250 vs 126 ms at 1 500)
     // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
     const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;
     // (the two-hop walk touches an order of magnitude more distinct nodes per hop: the 8192-tag table forgets
     // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
     // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
-    const uint32_t lds_until = use_hub ? 1200u : 512u;
+    const uint32_t lds_until = use_hub ? 1200u : dense ? 512u : 1500u;
     const int mode = idx->visited_mode == ROAR_VISITED_AUTO
                          ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                          : idx->visited_mode;
@@ -490,7 +496,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // then better spent on resident waves: 1 250 queries at L_pq = 500, 5.19 ms with 4 096 tags, 6.90 ms with 8 192).
         uint32_t want = 8192u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
-        else if ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000)) want = 16384u;
+        else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);

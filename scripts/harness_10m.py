@@ -1,6 +1,6 @@
 """The reference's evaluation run on FILES at the benchmark size, through this repo's C++ harness (own counterpart of
-tests/test_search_roargraph.cpp): T2I-10M shape written as base.fbin (8 GB) / query.fbin / groundtruth.ibin / roar.index,
-then `test_search_roargraph --L_pq 30 ...` -- the drop-in path end to end (file load, host buffers, one launch per L_pq).
+tests/test_search_roargraph.cpp): T2I-10M shape written as base.fbin (8 GB) / query.fbin / groundtruth.ibin / roar.index (bench.py's default graph),
+then `test_search_roargraph --L_pq 55 ...` -- the drop-in path end to end (file load, host buffers, one launch per L_pq).
 Prints the harness's own stdout (QPS column = wall clock of the call, results on the host)."""
 import argparse, os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,15 +10,14 @@ from mysteryann_amd import fileio, index as mi, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--dir", default="/tmp/roar_files")
-ap.add_argument("--L", type=int, nargs="+", default=[30, 30, 50, 100])
+ap.add_argument("--L", type=int, nargs="+", default=[55, 55, 100, 500])
 ap.add_argument("--gpus", type=str, default="")
 args = ap.parse_args()
 os.makedirs(args.dir, exist_ok=True)
 n, d, nq, k = args.n, 200, 10000, 10
-base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn
-print(f"# index built in {time.time() - t0:.0f}s, hash {idx.info('graph_hash') & (2**64 - 1):016x}", flush=True)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _graph import t2i_index
+idx, base, queries = t2i_index(n, nq, "reference", 0, "/tmp/r2_graph.index")
 gi, gd = idx.ExactKnnDevice(queries, 100)
 P = {x: os.path.join(args.dir, x) for x in ("base.fbin", "query.fbin", "gt.ibin", "roar.index", "eval.csv")}
 t0 = time.time()

@@ -10,15 +10,16 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--Ls", type=int, nargs="+", default=[100, 300, 500, 1000, 2000])
 ap.add_argument("--nqs", type=int, nargs="+", default=[1250, 10000])
 ap.add_argument("--out", default="gpurun_out/hub_ab.txt")
+ap.add_argument("--builder", default="reference")
+ap.add_argument("--graph-cache", default="/tmp/r2_graph.index")
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
 lines = []
 def say(s):
     print(s, flush=True); lines.append(s)
-base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn
-say(f"# n={n} index built in {time.time() - t0:.1f}s avg degree {idx.info('nedges') / n:.1f} max {idx.info('max_degree')}")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _graph import t2i_index
+idx, base, queries = t2i_index(n, 10000, args.builder, 0, args.graph_cache, say)
 idx.set_option("search_kernel", 1)
 def run(nq, L, vis, ve, hub, reps=3, tp=0):
     idx.set_option("visited_mode", vis); idx.set_option("vis_entries", ve); idx.set_option("hub_mode", 2 if hub else 1)

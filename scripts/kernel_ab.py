@@ -4,33 +4,26 @@ scanned are the reference algorithm's counters), TB/s in reference-algorithm byt
 instrumented kernel.  Output: gpurun_out/kernel_ab.txt"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from mysteryann_amd import index as mi, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--out", default="gpurun_out/kernel_ab.txt")
-ap.add_argument("--Ls", type=int, nargs="+", default=[30, 100, 300, 500, 1000, 2000])
+ap.add_argument("--Ls", type=int, nargs="+", default=[55, 100, 500, 2000])
 ap.add_argument("--nqs", type=int, nargs="+", default=[256, 1250, 2500, 10000])
-ap.add_argument("--builder", default="bootstrap", choices=["bootstrap", "reference"])
-ap.add_argument("--ref-learn", type=int, default=2_000_000)
+ap.add_argument("--builder", default="reference", choices=["bootstrap", "reference"])
+ap.add_argument("--ref-learn", type=int, default=0)
+ap.add_argument("--graph-cache", default="/tmp/r2_graph.index")
 ap.add_argument("--prof-Ls", type=int, nargs="*", default=None)
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
 lines = []
 def say(s):
     print(s, flush=True); lines.append(s)
-base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n if args.builder == "bootstrap" else args.ref_learn)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time()
-if args.builder == "bootstrap":
-    idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128)
-else:
-    lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
-    pp = mi.Parameters(); pp.Set("M_sq", 100); pp.Set("M_pjbp", 35); pp.Set("L_pjpq", 500)
-    idx.BuildRoarGraphDevice(lists, pp); del lists
-torch.cuda.synchronize(); del learn
-say(f"# n={n} index built in {time.time() - t0:.1f}s avg degree {idx.info('nedges') / n:.1f} max {idx.info('max_degree')}")
+from _graph import t2i_index
+idx, base, queries = t2i_index(n, 10000, args.builder, args.ref_learn, args.graph_cache, say)
 
 def run(nq, L, kern, vis, reps=3, ve=0, pool=0):
     idx.set_option("search_kernel", kern); idx.set_option("visited_mode", vis); idx.set_option("vis_entries", ve)
@@ -52,7 +45,7 @@ for L in args.Ls:
             cfgs += [(1, 1, 0, 0), (0, 1, 0, 0)]                  # LDS table: one wave, auto
             if nq <= 2500: cfgs += [(3, 1, 0, 0), (2, 1, 0, 0)]   # two / four waves
             if L <= 64: cfgs += [(1, 1, 0, 1)]                    # LDS pool instead of the register pool
-            if L >= 100: cfgs += [(1, 1, 16384, 0), (1, 1, 32768, 0)]
+
         for kern, vis, ve, pool in cfgs:
             out, ms = run(nq, L, kern, vis, ve=ve, pool=pool)
             ok = bool((out["ids"] == ref["ids"]).all() and (out["dists"] == ref["dists"]).all() and (out["hops"] == ref["hops"]).all())
@@ -63,9 +56,10 @@ for L in args.Ls:
 
 names = ["select", "adj", "filter", "score", "merge"]
 idx.set_option("profile_phases", 1)
-prof_cfg = ((30, 1), (100, 1), (500, 1), (500, 0), (2000, 0)) if args.prof_Ls is None else tuple((L, 1 if L < 512 else 0) for L in args.prof_Ls)
+prof_cfg = ((55, 1), (500, 1), (2000, 0)) if args.prof_Ls is None else tuple((L, 1 if L < 512 else 0) for L in args.prof_Ls)
 for L, vis in prof_cfg:
     for nq in (1, 1250, 10000):
+        idx.set_option("hub_mode", 1 if L > 64 else 0)  # (the instrumented hub form exists for one wave; keep the plain form here)
         out, ms = run(nq, L, 1, vis, reps=2)
         pr = idx.LastProfile(nq).astype(np.float64)
         H = out["hops"].double().sum().item()

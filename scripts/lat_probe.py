@@ -3,26 +3,28 @@ query, one query per CU and the strong-scaling batch (1250), per waves-per-query
 (the per-hop latencies are those of the 10 M set: both live in HBM far beyond the caches)."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from mysteryann_amd import index as mi, synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=2_000_000)
-ap.add_argument("--L", type=int, nargs="+", default=[30])
-ap.add_argument("--nqs", type=int, nargs="+", default=[1, 256, 1250])
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--builder", default="reference")
+ap.add_argument("--graph-cache", default="/tmp/r2_graph.index")
+ap.add_argument("--L", type=int, nargs="+", default=[55])
+ap.add_argument("--nqs", type=int, nargs="+", default=[1, 256, 1250, 2500, 10000])
 ap.add_argument("--vis", type=int, default=1)
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
-base, queries, learn = synth.t2i_torch(n, 10000, d, n_learn=n)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn
-print(f"# n={n} built in {time.time() - t0:.1f}s avg degree {idx.info('nedges') / n:.1f}", flush=True)
+from _graph import t2i_index
+idx, base, queries = t2i_index(n, 10000, args.builder, 0, args.graph_cache)
 idx.set_option("visited_mode", args.vis)
 names = ["select", "adj", "filter", "score", "merge"]
 for L in args.L:
     for nq in args.nqs:
         q = queries[:nq].contiguous()
         for kern in (1, 3, 2):
+            if kern != 1 and nq > 2500: continue
             idx.set_option("search_kernel", kern)
             idx.set_option("profile_phases", 0)
             best = 1e9

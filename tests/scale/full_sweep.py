@@ -18,24 +18,25 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--cpu-queries", type=int, default=2000)
 ap.add_argument("--out", default="gpurun_out/sweep_t2i10m.csv")
 ap.add_argument("--no-cpu", action="store_true")
+ap.add_argument("--builder", default="reference")
+ap.add_argument("--graph-cache", default="/tmp/r2_graph.index")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
-base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=n)
-idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None); idx.SetBaseData(base)
-t0 = time.time(); idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128); torch.cuda.synchronize(); del learn  # bench.py defaults
-print(f"index built in {time.time() - t0:.1f}s, avg degree {idx.info('nedges') / n:.1f}", flush=True)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scripts"))
+from _graph import t2i_index
+idx, base, queries = t2i_index(n, nq, args.builder, 0, args.graph_cache)
 gt = idx.ExactKnnDevice(queries, k, want_dists=False)[0].to(torch.int64)
 impl = "ref" if oracle.have_ref() else "port"
 threads = min(oracle.max_threads(impl), bench.effective_cpus())
 hb = base.cpu().numpy(); ep, off, nbrs = idx.GetProjectionGraph(); hq = queries.cpu().numpy()
 cpu_L = {10, 20, 50, 60, 100, 200, 500, 1000, 2000}
-rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,kernel_cmps,vis_entries,grid,roofline_frac,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
+rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,kernel_cmps,vis_entries,hub_bitmap,grid,roofline_frac,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
 ap_cpu = not args.no_cpu
 for L in bench.L_LIST:
     for _ in range(2): out = idx.SearchRoarGraphBatchDevice(queries, k, L)
     torch.cuda.synchronize()
     ms = idx.info("last_kernel_ns") / 1e6
-    mode, ve, grid = idx.info("last_visited_mode"), idx.info("last_vis_entries"), idx.info("last_grid")
+    mode, ve, grid, hubf = idx.info("last_visited_mode"), idx.info("last_vis_entries"), idx.info("last_grid"), idx.info("last_hub_bitmap")
     rec = bench.recall_at_k(torch, out["ids"], gt, k)
     idx.set_option("visited_mode", 0)  # the reference algorithm's counters
     ex = idx.SearchRoarGraphBatchDevice(queries, k, L); torch.cuda.synchronize()
@@ -51,7 +52,7 @@ for L in bench.L_LIST:
         gi = out["ids"][:m].cpu().numpy().view(np.uint32); gd = out["dists"][:m].cpu().numpy()
         same = f"{float(((gi == o['ids']).all(axis=1) & (gd == o['dists']).all(axis=1)).mean()):.4f}"
     rows.append(f"{L},{nq / ms * 1e3:.0f},{float(ex['cmps'].float().mean()):.1f},{ms / nq:.6f},{rec:.4f},"
-                f"{float(out['hops'].float().mean()):.2f},{'lds' if mode == 1 else 'exact'},{float(out['cmps'].float().mean()):.1f},{ve},{grid},"
+                f"{float(out['hops'].float().mean()):.2f},{'lds' if mode == 1 else 'exact'},{float(out['cmps'].float().mean()):.1f},{ve},{hubf},{grid},"
                 f"{alg / (ms * 1e-3) / 8e12:.3f},{cpu_qps},{threads if cpu_qps else ''},{same}")
     print(rows[-1], flush=True)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)

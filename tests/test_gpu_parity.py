@@ -194,7 +194,7 @@ def test_forgetful_visited_table_keeps_results(built_lib):
     assert np.array_equal(r["dists"], o["dists"])
     assert np.array_equal(r["hops"], o["hops"])
     assert (r["cmps"] >= o["cmps"]).all() and (r["cmps"] > o["cmps"]).any()
-    idx.set_option("hub_mode", 0)  # ... and then nothing is ever forgotten, however small the table
+    idx.set_option("hub_mode", 2)  # ... and then nothing is ever forgotten, however small the table
     r = idx.SearchRoarGraphBatch(q, K, 150)
     assert idx.info("last_hub_bitmap") == 1
     assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["cmps"], o["cmps"])
@@ -466,27 +466,30 @@ def test_exact_knn_query_block_larger_than_one_launch(built_lib):
 
 
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
-    """Default policy: on-chip tag table below L_pq = 1200 (the hub bitmap carries the busiest nodes from L_pq = 100),
-    HBM epoch tags from there on; without the hub form (option, or a graph with a row longer than 170) the switch is at
-    512.  All give the reference's results."""
+    """Default policy (plan_search): a dense graph (average degree >= 24) takes the hub-bitmap form from L_pq = 100 and
+    the on-chip tag table below L_pq = 1200 (512 without the hub form), a sparse one the plain form with the table
+    below 1500; HBM epoch tags beyond.  All give the reference's results."""
     import oracle
     from mysteryann_amd import index as mi
 
     n, d, nq = 5000, 128, 20
-    base, q, off, nbrs = _random_case(n, d, nq, 0, seed=21, maxdeg=40)
-    idx = mi.IndexBipartite(d, n, 0, None)
-    idx.SetBaseData(base)
-    idx.SetProjectionGraph(9, off, nbrs)
-    assert idx.info("visited_mode") == 2
-    for hub_mode, cases in ((0, ((50, 1, 0), (99, 1, 0), (100, 1, 1), (1199, 1, 1), (1200, 0, 1), (1500, 0, 1))),
-                            (1, ((50, 1, 0), (511, 1, 0), (512, 0, 0), (900, 0, 0)))):
-        idx.set_option("hub_mode", hub_mode)
-        for L, want_mode, want_hub in cases:
-            r = idx.SearchRoarGraphBatch(q, K, L)
-            assert idx.info("last_visited_mode") == want_mode and idx.info("last_hub_bitmap") == want_hub, (hub_mode, L)
-            o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
-            assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
-            assert np.array_equal(r["hops"], o["hops"])
+    for maxdeg, plan in ((80, ((0, ((50, 1, 0), (99, 1, 0), (100, 1, 1), (1199, 1, 1), (1200, 0, 1), (1500, 0, 1))),
+                               (1, ((50, 1, 0), (511, 1, 0), (512, 0, 0), (900, 0, 0))))),      # average degree ~ 39: dense
+                         (30, ((0, ((50, 1, 0), (300, 1, 0), (1499, 1, 0), (1500, 0, 0))),),)):  # ~ 14: sparse
+        base, q, off, nbrs = _random_case(n, d, nq, 0, seed=21, maxdeg=maxdeg)
+        idx = mi.IndexBipartite(d, n, 0, None)
+        idx.SetBaseData(base)
+        idx.SetProjectionGraph(9, off, nbrs)
+        assert idx.info("visited_mode") == 2
+        for hub_mode, cases in plan:
+            idx.set_option("hub_mode", hub_mode)
+            for L, want_mode, want_hub in cases:
+                r = idx.SearchRoarGraphBatch(q, K, L)
+                assert idx.info("last_visited_mode") == want_mode and idx.info("last_hub_bitmap") == want_hub, (maxdeg, hub_mode, L)
+                o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
+                assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
+                assert np.array_equal(r["hops"], o["hops"])
+        idx.close()
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])

@@ -269,8 +269,8 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq; power of two)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
- *                    3 two waves per query; auto picks four waves while the whole batch is resident that way,
- *                    else two waves while it is resident that way, else one
+ *                    3 two waves per query; auto picks four waves for batches of at most one query per CU on a dense
+ *                    graph (average degree >= 24), one wave otherwise
  *   "pool_form"      0 auto (candidate pool in a register pair of wave 0 for L_pq <= 64, in LDS beyond) | 1 always LDS
  *   "hub_mode"       0 auto | 1 off | 2 on: the 65 535 highest-in-degree nodes keep their visited bits in an exact
  *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row

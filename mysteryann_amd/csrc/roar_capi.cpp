@@ -568,17 +568,21 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         if (e) return e;
         picked = true;
     } else if (idx->search_kernel != 1 && !idx->building) {
-        // four waves per query while the whole batch is resident that way, else two waves per query while it is
-        // resident that way, else one (search_kernel: 0 auto, 1 one wave, 2 four waves, 3 two waves)
+        // search_kernel: 0 auto, 1 one wave per query, 2 four waves, 3 two waves.  Auto: four waves for batches of at most
+        // one query per CU on a dense graph (a hop gathers ~100 rows: one pass instead of three -- 256 queries at L_pq = 30
+        // on the T2I-10M bootstrap graph 0.305 vs 0.329 ms); one wave otherwise.  On a sparse graph a hop gathers ~50 rows
+        // and the extra waves only add barriers (256 queries at L_pq = 55: 0.353 ms with one wave, 0.369 with four), and from a
+        // few hundred queries on the one-wave form is ahead everywhere (1 250 queries: 0.549 vs 0.557 ms with two waves).
         for (int w : {4, 2}) {
             if (idx->search_kernel == 2 && w != 4) continue;
             if (idx->search_kernel == 3 && w != 2) continue;
+            if (idx->search_kernel == 0 && (w != 4 || !dense || nq > (uint64_t)idx->n_cus)) continue;
             sel.waves = w;
             if (sel.prof && sel.hub) continue;  // (the instrumented hub form exists for one wave per query)
             int occ_mw = 0;
             int e = occupancy(&occ_mw);
             if (e) return e;
-            if (occ_mw >= 1 && (idx->search_kernel != 0 || nq <= (uint64_t)occ_mw * (uint64_t)idx->n_cus)) {
+            if (occ_mw >= 1) {
                 occ = occ_mw;
                 picked = true;
                 break;

@@ -295,34 +295,33 @@ __device__ __forceinline__ void merge_regpool(u64 &pk, uint32_t &psize, const u6
                                               int lane) {
     const u64 FLAG = 1ull;
     const u64 ci = (uint32_t)lane < cnt ? ck[lane] : ~0ull;
-    bool valid = (uint32_t)lane < cnt;
-    if (psize == L) valid = valid && ci < (lane_u64(pk, (int)L - 1) & ~FLAG);
-    const u64 todo = __ballot(valid);
+    bool ok = (uint32_t)lane < cnt;
+    if (psize == L) ok = ok && ci < (lane_u64(pk, (int)L - 1) & ~FLAG);
+    const u64 todo = __ballot(ok);
     if (todo == 0) return;
-    const bool inpool = (uint32_t)lane < psize;
+    // lanes past the pool hold ~0: their masked key is above every candidate's (ids are below 2^31 - 1), so the
+    // compares below need no "is a pool entry" term.  Everything indexed by j is wave-uniform and stays in SGPRs.
     const u64 pkm = pk & ~FLAG;
+    u64 keep = todo;
     uint32_t r = 0, shift = 0, lo_mine = 0;
-    u64 dead = 0;  // candidates found to repeat an earlier candidate's key (cannot happen within one adjacency row)
-    for (u64 it = todo; it;) {
+    for (u64 it = todo; it; it &= it - 1) {
         const int j = __ffsll((long long)it) - 1;
-        it &= it - 1;
-        if ((dead >> j) & 1ull) continue;
         const u64 kj = lane_u64(ci, j);
-        const u64 below = __ballot(inpool && pkm < kj);
-        if (__ballot(inpool && pkm == kj)) {  // already in the pool
-            if (lane == j) valid = false;
-            continue;
-        }
-        const u64 rep = __ballot(valid && lane > j && ci == kj);
-        dead |= rep;
-        if ((rep >> lane) & 1ull) valid = false;
-        const uint32_t lo_j = (uint32_t)__popcll(below);
-        if (lane == j) lo_mine = lo_j;
-        r += (kj < ci) ? 1u : 0u;
-        shift += (lo_j <= (uint32_t)lane) ? 1u : 0u;
+        const u64 rep = __ballot(ci == kj) & (0ull - (2ull << j));  // the same key again further up (rows are deduplicated: never)
+        keep &= ~rep;
+        it &= ~rep;
+        const bool dup = __ballot(pkm == kj) != 0;  // already in the pool (neighbor.h:161-162)
+        const uint32_t lo_j = (uint32_t)__popcll(__ballot(pkm < kj));
+        keep &= dup ? ~(1ull << j) : ~0ull;
+        const u64 kje = dup ? ~0ull : kj;             // a dropped candidate ranks nobody ...
+        const uint32_t loe = dup ? 0xFFFFFFFFu : lo_j;  // ... and moves nobody
+        lo_mine = (lane == j) ? lo_j : lo_mine;
+        r += (kje < ci) ? 1u : 0u;
+        shift += (loe <= (uint32_t)lane) ? 1u : 0u;
     }
-    const uint32_t s = (uint32_t)__popcll(__ballot(valid));
-    if (inpool && (uint32_t)lane + shift < L) scratch[(uint32_t)lane + shift] = pk;
+    const bool valid = (keep >> lane) & 1ull;
+    const uint32_t s = (uint32_t)__popcll(keep);
+    if ((uint32_t)lane < psize && (uint32_t)lane + shift < L) scratch[(uint32_t)lane + shift] = pk;
     if (valid && lo_mine + r < L) scratch[lo_mine + r] = ci;
     psize = (psize + s < L) ? psize + s : L;
     wave_sync();

@@ -23,41 +23,48 @@
 //
 // The kernel is HBM-gather bound (0.5 flop/byte): nothing here goes through MFMA on purpose.
 #pragma once
+#include <type_traits>
+
 #include "roar_wave.h"
 
 namespace {
 
-// LDS visited table, test-and-set of up to three ids per lane at once (one adjacency round trip).  Same table as
+// LDS visited table, test-and-set of NC (1..3) ids per lane at once (one adjacency round trip; NC = the 64-word chunks
+// of the row that hold neighbours -- a row of at most 63 neighbours, the common case on a sparse graph, is one chunk).  Same table as
 // visited_filter<VIS_LDS> -- sets x 4 ways of u16 tags, (set, tag) <-> id a bijection, so a hit is never false -- but an
 // empty way is claimed with a 32-bit compare-and-swap on the half of the set that holds it: no write / barrier /
 // re-read round per insertion; a lane that loses a race sees the winner's word in the CAS result and tries the next
 // way.  The three probes of a lane are independent, so a round is written branch-free with the three atomics in
 // flight together.  A full set overwrites a victim way; that is the only place the table forgets (the node is then
 // scored again and its key is dropped by the merge as a duplicate or as worse than the pool's last entry).
-__device__ __forceinline__ void visited_lds3(const bool (&isn)[3], const uint32_t (&nb)[3], uint16_t *vis, uint32_t sets_mask,
-                                             uint32_t sets_log2, bool (&fresh)[3]) {
-    uint32_t *w[3];
-    uint32_t tag[3], x[3], y[3];
-    bool pend[3];
+template <int NC>
+__device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
+                                             uint32_t sets_log2, bool (&fresh)[NC]) {
+    uint32_t *w[NC];
+    uint32_t tag[NC], x[NC], y[NC];
+    bool pend[NC];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint32_t set = nb[c] & sets_mask;
         tag[c] = (nb[c] >> sets_log2) + 1u;
         w[c] = reinterpret_cast<uint32_t *>(vis + 4 * set);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const uint2 ww = *reinterpret_cast<const uint2 *>(w[c]);
         x[c] = ww.x;
         y[c] = ww.y;
         pend[c] = isn[c];
         fresh[c] = false;
     }
-    while (__ballot(pend[0] | pend[1] | pend[2])) {
-        bool cas[3], low[3];
-        uint32_t oldw[3], got[3];
+    bool any = false;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NC; ++c) any |= isn[c];
+    while (__ballot(any)) {
+        bool cas[NC], low[NC];
+        uint32_t oldw[NC], got[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
             const uint32_t t0 = x[c] & 0xFFFFu, t1 = x[c] >> 16, t2 = y[c] & 0xFFFFu, t3 = y[c] >> 16;
             const bool hit = (t0 == tag[c]) | (t1 == tag[c]) | (t2 == tag[c]) | (t3 == tag[c]);
             const bool full = (t0 != 0) & (t1 != 0) & (t2 != 0) & (t3 != 0);
@@ -71,11 +78,11 @@ __device__ __forceinline__ void visited_lds3(const bool (&isn)[3], const uint32_
             got[c] = oldw[c];
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < NC; ++c)
             if (cas[c])
                 got[c] = atomicCAS(w[c] + (low[c] ? 0 : 1), oldw[c], oldw[c] | (((oldw[c] & 0xFFFFu) == 0) ? tag[c] : (tag[c] << 16)));
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const bool won = cas[c] & (got[c] == oldw[c]);
             fresh[c] |= won;
             pend[c] &= !won;
@@ -84,6 +91,9 @@ __device__ __forceinline__ void visited_lds3(const bool (&isn)[3], const uint32_
                 else y[c] = got[c];
             }
         }
+        any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) any |= pend[c];
     }
 }
 
@@ -410,57 +420,67 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 }
                 if (!done) {
                     // visited filter over the whole round trip (index_bipartite.cpp:2378-2385), survivors packed in cid
-                    uint32_t nb[3];
-                    bool isn[3];
+                    // (chunks of 64 words; only those that hold neighbours are looked at: a row of at most 63
+                    // neighbours -- the common case on a sparse graph -- costs a third of the filter's instructions)
+                    auto run_filter = [&](auto nc_tag) {
+                        constexpr int NC = decltype(nc_tag)::value;
+                        uint32_t nb[NC];
+                        bool isn[NC];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const uint32_t w = wpos + 64u * (uint32_t)c + (uint32_t)lane;
-                        isn[c] = w >= 1 && w <= deg;
-                        nb[c] = isn[c] ? (c == 0 ? a0 : c == 1 ? a1 : a2) : 0u;
-                    }
-                    if (PROF) {
-                        c1 = (long long)__builtin_readcyclecounter();
-                        t_adj += c1 - c0;
-                        c0 = c1;
-                    }
-                    bool hfresh[3] = {false, false, false};
-                    if (HUB) {
-                        // the slots sit behind the ids, two per word: pass the four registers through LDS to index them
-                        rowbuf[lane] = a0, rowbuf[64 + lane] = a1, rowbuf[128 + lane] = a2, rowbuf[192 + lane] = a3;
-                        wave_sync();
+                        for (int c = 0; c < NC; ++c) {
+                            const uint32_t w = wpos + 64u * (uint32_t)c + (uint32_t)lane;
+                            isn[c] = w >= 1 && w <= deg;
+                            nb[c] = isn[c] ? (c == 0 ? a0 : c == 1 ? a1 : a2) : 0u;
+                        }
+                        if (PROF) {
+                            c1 = (long long)__builtin_readcyclecounter();
+                            t_adj += c1 - c0;
+                            c0 = c1;
+                        }
+                        bool hfresh[NC];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const uint32_t j = 64u * (uint32_t)c + (uint32_t)lane - 1u;  // neighbour index of word w
-                            const bool hub = isn[c] && j < nhub;
-                            if (hub) {
-                                const uint32_t slot = (rowbuf[1 + deg + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
-                                const uint32_t bit = 1u << (slot & 31);
-                                hfresh[c] = (atomicOr(&hbits[slot >> 5], bit) & bit) == 0;
-                                isn[c] = false;  // settled: the filters below see only the other neighbours
+                        for (int c = 0; c < NC; ++c) hfresh[c] = false;
+                        if (HUB) {
+                            // the slots sit behind the ids, two per word: pass the four registers through LDS to index them
+                            rowbuf[lane] = a0, rowbuf[64 + lane] = a1, rowbuf[128 + lane] = a2, rowbuf[192 + lane] = a3;
+                            wave_sync();
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                const uint32_t j = 64u * (uint32_t)c + (uint32_t)lane - 1u;  // neighbour index of word w
+                                const bool hub = isn[c] && j < nhub;
+                                if (hub) {
+                                    const uint32_t slot = (rowbuf[1 + deg + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                                    const uint32_t bit = 1u << (slot & 31);
+                                    hfresh[c] = (atomicOr(&hbits[slot >> 5], bit) & bit) == 0;
+                                    isn[c] = false;  // settled: the filters below see only the other neighbours
+                                }
                             }
+                            wave_sync();
                         }
-                        wave_sync();
-                    }
-                    bool fresh[3];
-                    if (MODE == VIS_EXACT) {  // visited_array[nbr] != tag ... = tag  (:2378,2385)
-                        uint32_t tg[3];  // the three loads are issued together (a lane without a neighbour reads tag 0)
+                        bool fresh[NC];
+                        if (MODE == VIS_EXACT) {  // visited_array[nbr] != tag ... = tag  (:2378,2385)
+                            uint32_t tg[NC];  // the loads are issued together (a lane without a neighbour reads tag 0)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) tg[c] = __builtin_nontemporal_load(tags + (isn[c] ? nb[c] : 0u));
+                            for (int c = 0; c < NC; ++c) tg[c] = __builtin_nontemporal_load(tags + (isn[c] ? nb[c] : 0u));
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            fresh[c] = isn[c] && tg[c] != epoch;
-                            if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
+                            for (int c = 0; c < NC; ++c) {
+                                fresh[c] = isn[c] && tg[c] != epoch;
+                                if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
+                            }
+                        } else {
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, p.vis_sets_log2, fresh);
                         }
-                    } else {
-                        visited_lds3(isn, nb, vis, sets_mask, p.vis_sets_log2, fresh);
-                    }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const bool f = fresh[c] | hfresh[c];
-                        const u64 fm = __ballot(f);
-                        if (f) cid[m + lanes_below(fm)] = nb[c];
-                        m += (uint32_t)__popcll(fm);
-                    }
+                        for (int c = 0; c < NC; ++c) {
+                            const bool f = fresh[c] | hfresh[c];
+                            const u64 fm = __ballot(f);
+                            if (f) cid[m + lanes_below(fm)] = nb[c];
+                            m += (uint32_t)__popcll(fm);
+                        }
+                    };
+                    if (!HUB && deg < wpos + 64u) run_filter(std::integral_constant<int, 1>());
+                    else if (!HUB && deg < wpos + 128u) run_filter(std::integral_constant<int, 2>());
+                    else run_filter(std::integral_constant<int, 3>());
                     wpos += HUB ? 256u : 192u;
                     cmps += m;  // ++cmps per scored neighbour, :2397
                     // Next adjacency words, in flight while this round trip's rows are scored: the rest of this row

@@ -162,7 +162,9 @@ def test_high_degree_rows_and_large_pool(built_lib):
     idx.SetProjectionGraph(5, off, nbrs)
     for mode in (0, 1):
         idx.set_option("visited_mode", mode)
-        for L, k in ((2000, 10), (100, 100), (1, 1)):
+        # (5000: a pool beyond 4 096 entries takes the pieced second level of the merge's search; the 6 000-node graph
+        # never fills it, so this is also the short-of-L_pq pool)
+        for L, k in ((2000, 10), (100, 100), (1, 1), (5000, 10), (600, 7)):
             o = oracle.search_batch(base, off, nbrs, 5, q, k, L, 1)
             r = idx.SearchRoarGraphBatch(q, k, L)
             assert np.array_equal(r["ids"], o["ids"]), (mode, L)

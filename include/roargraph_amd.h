@@ -270,11 +270,11 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
  *                    3 two waves per query; auto picks four waves for batches of at most one query per CU on a dense
- *                    graph (average degree >= 24), one wave otherwise
+ *                    graph (average degree x row bytes >= 24 x 800), one wave otherwise
  *   "pool_form"      0 auto (candidate pool in a register pair of wave 0 for L_pq <= 64, in LDS beyond) | 1 always LDS
  *   "hub_mode"       0 auto | 1 off | 2 on: the 65 535 highest-in-degree nodes keep their visited bits in an exact
  *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row
- *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on graphs of average degree >= 24;
+ *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on dense graphs (same measure);
  *                    results do not depend on it
  *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)

@@ -458,7 +458,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     //     graph, 10 000 queries, 8 192 tags / 4 096 tags + hub bitmap / 16 384 tags / HBM tags: L_pq = 100 6.17 / 6.14 /
     //     6.63 / 7.82 ms, 500 26.0 / 26.1 / 28.4 / 33.8, 1 000 55.0 / 55.6 / 74.8 / 63.9, 1 400 78.3 / 79.0 / 108.9 / 85.7,
     //     2 000 131.0 / 134.7 / 162.9 / 116.0 ms (profiles/r02_hub_forms*.txt).
-    const bool dense = idx->gn && (double)idx->nedges / (double)idx->gn >= 24.0;
+    // ("dense" is about the bytes a hop gathers -- average degree x row bytes, with 24 rows of 800 B as the line: a
+    // 128-d graph of average degree 32 gathers 16 KB per hop and behaves like a sparse one: SIFT-1M shape, L_pq = 170,
+    // hub form with five waves per CU 9.59 ms, plain form with eight 8.0 ms)
+    const bool dense = idx->gn && (double)idx->nedges / (double)idx->gn * (double)idx->dim_pad * 4.0 >= 24.0 * 800.0;
     bool use_hub = false;
     if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
         int e = ensure_hub_rows(idx);

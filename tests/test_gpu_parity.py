@@ -468,7 +468,7 @@ def test_exact_knn_query_block_larger_than_one_launch(built_lib):
 
 
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
-    """Default policy (plan_search): a dense graph (average degree >= 24) takes the hub-bitmap form from L_pq = 100 and
+    """Default policy (plan_search): a dense graph (average degree x row bytes >= 24 x 800) takes the hub-bitmap form from L_pq = 100 and
     the on-chip tag table below L_pq = 1200 (512 without the hub form), a sparse one the plain form with the table
     below 1500; HBM epoch tags beyond.  All give the reference's results."""
     import oracle

@@ -134,6 +134,9 @@ def main():
                          "training queries as base points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (drop-in) timing")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of measure_traffic()
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
     ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
@@ -240,6 +243,17 @@ def main():
         f"max degree {idx.info('max_degree')}, ep {idx.info('ep')}, adjacency stride {idx.info('adj_stride')} words, "
         f"hash {graph_hash:016x}")
     del learn
+
+    if args.pmc_child:  # profiled child of measure_traffic(): the timed loop's launches and nothing else
+        if not cached or not args.L:
+            raise SystemExit("--pmc-child needs --graph-cache (an existing file) and --L")
+        idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2}[args.visited])
+        if args.vis_entries:
+            idx.set_option("vis_entries", args.vis_entries)
+        for s_ in range(args.warmup + args.steps):
+            idx.SearchRoarGraphBatchDevice(batches[s_ % B] if s_ >= args.warmup else batches[0], args.k, args.L)
+        torch.cuda.synchronize()
+        return
 
     t0 = time.time()
     gts = []
@@ -410,13 +424,27 @@ def main():
                      "mfma_util": 0.0},
     }
 
-    # HBM traffic per launch: PMC counters cannot be read from inside the process; the figure comes from a separate
-    # rocprofv3 --pmc capture of this same command (scripts/profile_r2.sh -> profiles/*_search_kernel_summary.json) and
-    # is quoted only for the same workload, L_pq and graph (hash); else null.
+    # HBM traffic per launch.  PMC counters cannot be read from inside the process, so rank 0 of a one-GPU run profiles a
+    # child of itself: `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --pmc-child ...` and the same for
+    # WRITE_SIZE (the two do not fit one pass), same data (seed), same graph (file), same L_pq, same rotating batches.
+    # If that is not possible here the figure of a stored capture of the same command (scripts/profile_r2.sh ->
+    # profiles/*_search_kernel_summary.json) is quoted for the same workload, L_pq and graph hash; else null.
+    if world == 1 and rank == 0 and not args.no_traffic:
+        try:
+            t0 = time.time()
+            tr = measure_traffic(args, idx, chosen, mine)
+            if tr:
+                result["roofline"].update(tr)
+                log(f"[rank 0] PMC traffic per launch {tr['traffic'] / 1e9:.2f} GB = {tr['traffic'] / bytes_per_launch:.3f} x algorithmic "
+                    f"({time.time() - t0:.0f}s for the two profiled child passes)")
+        except Exception as e:  # noqa: BLE001
+            log(f"[rank 0] PMC traffic not measured in this run: {e}")
     try:
         import glob
 
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_search_kernel_summary.json")))[::-1]:
+            if result["roofline"]["traffic"] is not None:
+                break
             s = json.load(open(f))
             c = s["bench_line"]["config"]
             if (c["workload"] == result["config"]["workload"] and c["L_pq"] == chosen
@@ -436,6 +464,61 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def counter_per_launch(csv_path, counter, steps):
+    """Mean of `counter` over the last `steps` dispatches of the search kernel in a rocprofv3 counter_collection.csv (the
+    timed loop is the last thing the profiled child launches; the builder's searches run under their own kernel name)."""
+    import csv
+
+    rows = [x for x in csv.DictReader(open(csv_path))
+            if "roar_search_v2_kernel" in x["Kernel_Name"] and "build" not in x["Kernel_Name"]
+            and x.get("Counter_Name", counter) == counter]
+    if len(rows) < steps:
+        raise RuntimeError(f"{len(rows)} profiled launches of the search kernel in {csv_path}, expected at least {steps}")
+    return sum(float(x["Counter_Value"]) for x in rows[-steps:]) / steps
+
+
+def measure_traffic(args, idx, L, nq_launch):
+    """FETCH_SIZE / WRITE_SIZE of the search kernel's timed launches, from two profiled child runs of this script
+    (MI355X_MICROARCH.md: separate --pmc passes with --kernel-trace only; FETCH_SIZE counts 128-B requests at 64 B on
+    gfx950 -> x2, calibrated on this access pattern in profiles/r01_fetch_calibration.txt).  The child is started as a
+    child process (never exec'ed over this one), the interpreter itself after `--`."""
+    import glob, shutil, subprocess, tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    own_cache = not (args.graph_cache and os.path.exists(args.graph_cache))
+    cache = args.graph_cache if not own_cache else tempfile.mktemp(prefix="roar_bench_graph_", suffix=".index", dir="/tmp")
+    if own_cache:
+        idx.SaveProjectionGraph(cache)
+    steps = 8
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
+             "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
+             "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
+             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="roar_pmc_", dir="/tmp")
+            try:
+                r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
+                                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+                files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}")
+                vals[counter] = counter_per_launch(max(files, key=os.path.getmtime), counter, steps)  # KB per launch
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
+    finally:
+        if own_cache and os.path.exists(cache):
+            os.remove(cache)
+    return {"traffic": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+            "traffic_source": f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {steps} launches of a "
+                              f"child of this command (same data, graph, L_pq, batches); FETCH_SIZE x 2 (gfx950)",
+            "FETCH_SIZE_KB_raw_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw_per_launch": vals["WRITE_SIZE"]}
 
 
 def host_buffer_path(np, torch, idx, batches, outs, args, L):
@@ -493,7 +576,7 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
 
     d, k, nq = 200, args.k, args.nq
     m = args.n_explicit or 12_500_000  # points per shard
-    n_learn = args.learn if args.learn >= 0 else m // 10
+    n_learn = args.learn if args.learn >= 0 else (m // 5 if args.builder == "reference" else m // 10)
     t0 = time.time()
     A, _, sc = synth._maps(d, args.seed)  # one distribution for all shards, own latent draws per shard
     g = torch.Generator(device=dev)
@@ -507,7 +590,14 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
     _, queries, learn = synth.t2i_torch(1024, nq, d, seed=args.seed, n_learn=n_learn, device=dev)  # same queries on every rank
     idx = mi.IndexBipartite(d, m, mi.INNER_PRODUCT, None, device=dev.index or 0)
     idx.SetBaseData(base)
-    idx.BuildBootstrapGraph(learn=learn, max_degree=args.build_maxdeg, row_keep=args.build_keep)
+    if args.builder == "reference":  # exact lists of the training queries on this shard -> LinkProjection, canonical parameters
+        lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
+        prm = mi.Parameters()
+        prm.Set("M_sq", 100); prm.Set("M_pjbp", 35); prm.Set("L_pjpq", 500)
+        idx.BuildRoarGraphDevice(lists, prm)
+        del lists
+    else:
+        idx.BuildBootstrapGraph(learn=learn, max_degree=args.build_maxdeg, row_keep=args.build_keep)
     torch.cuda.synchronize()
     del learn
     log(f"[rank {rank}] shard of {m} points generated and indexed in {time.time() - t0:.1f}s, avg degree "
@@ -580,9 +670,9 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
                    "metric": "ip", "n_queries": nq, "k": k, "L_pq": chosen, "recall_at_10": rec,
                    "parallelism": f"base + graph sharded {world}-way, all queries on every shard, RCCL all-gather of "
                                   f"{nq * k * 8} B per rank + HIP top-k merge",
-                   "avg_degree": idx.info("nedges") / m},
+                   "builder": args.builder, "avg_degree": idx.info("nedges") / m},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "roar_search_kernel (this rank's shard)", "kernel_ms": kernel_ms,
+                     "traffic": None, "kernel": "roar_search_v2_kernel (this rank's shard)", "kernel_ms": kernel_ms,
                      "exchange_and_merge_ms": ms_per_step - kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "queries_per_launch": nq, "mfma_util": 0.0},
     }

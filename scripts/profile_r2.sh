@@ -13,7 +13,7 @@ rm -f /tmp/r2_graph.index
 python3 bench.py --graph-cache /tmp/r2_graph.index > $O/bench.json 2> $O/bench.err
 tail -3 $O/bench.err; cat $O/bench.json
 export TMPDIR=/tmp
-ARGS="--graph-cache /tmp/r2_graph.index --steps 8 --warmup 1 --no-cpu-baseline --no-host-path --L $(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['L_pq'])")"
+ARGS="--graph-cache /tmp/r2_graph.index --steps 8 --warmup 1 --no-cpu-baseline --no-host-path --no-traffic --L $(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['L_pq'])")"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $ARGS > $O/trace.json 2> $O/trace.err
 echo "trace rc=$?"; tail -2 $O/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $ARGS > $O/pmc_fetch.json 2> $O/pmc_fetch.err

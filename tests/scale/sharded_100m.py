@@ -19,10 +19,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shards", type=int, default=8)
 ap.add_argument("--per-shard", type=int, default=12_500_000)
 ap.add_argument("--nq", type=int, default=10_000)
-ap.add_argument("--L", type=int, nargs="+", default=[10, 15, 20, 30], help="L_pq values, all on one build per shard")
+ap.add_argument("--L", type=int, nargs="+", default=[15, 20, 30, 40, 55], help="L_pq values, all on one build per shard")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--check", type=int, default=200)
-ap.add_argument("--learn", type=int, default=1_250_000)
+ap.add_argument("--builder", default="reference", choices=["reference", "bootstrap"])
+ap.add_argument("--learn", type=int, default=0, help="training queries per shard (0 = per-shard / 5 for the reference builder, / 10 for bootstrap)")
 ap.add_argument("--maxdeg", type=int, default=384)
 ap.add_argument("--keep", type=int, default=128)
 args = ap.parse_args()
@@ -49,10 +50,17 @@ for s in range(S):
         mm = min(1 << 20, m - i)
         base[i:i + mm] = torch.randn((mm, synth.LATENT), generator=g, device="cuda") @ At \
             + (0.3 * float(sc)) * torch.randn((mm, d), generator=g, device="cuda")
-    _, _, learn = synth.t2i_torch(1024, 1, d, seed=1234, n_learn=args.learn)
+    n_learn = args.learn or (m // 5 if args.builder == "reference" else m // 10)
+    _, _, learn = synth.t2i_torch(1024, 1, d, seed=1234, n_learn=n_learn)
     idx = mi.IndexBipartite(d, m, mi.INNER_PRODUCT, None)
     idx.SetBaseData(base)
-    idx.BuildBootstrapGraph(learn=learn, max_degree=args.maxdeg, row_keep=args.keep)
+    if args.builder == "reference":  # exact lists of the training queries on this shard -> the reference's LinkProjection, canonical parameters
+        lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
+        prm = mi.Parameters(); prm.Set("M_sq", 100); prm.Set("M_pjbp", 35); prm.Set("L_pjpq", 500)
+        idx.BuildRoarGraphDevice(lists, prm)
+        del lists
+    else:
+        idx.BuildBootstrapGraph(learn=learn, max_degree=args.maxdeg, row_keep=args.keep)
     torch.cuda.synchronize()
     build_s.append(time.time() - t0)
     del learn
@@ -98,7 +106,7 @@ for L in Ls:
                   "max_abs_dist_diff": float(np.abs(got_d - want_d).max()), "cpu_impl": impl}
     total_ms = sum(kern_ms[L]) + merge_ms
     print(json.dumps({
-        "config": f"t2i-{S * m // 1_000_000}M-ip index-sharded x{S} (one GPU, shards back to back)", "n_base": S * m,
+        "config": f"t2i-{S * m // 1_000_000}M-ip index-sharded x{S} (one GPU, shards back to back)", "builder": args.builder, "n_base": S * m,
         "per_shard": m, "n_queries": args.nq, "k": k, "L_pq": L, "recall_at_10_global": recall,
         "search_kernel_ms_per_shard": kern_ms[L], "merge_kernel_ms": merge_ms,
         "single_gpu_serial_qps": args.nq / (total_ms * 1e-3),

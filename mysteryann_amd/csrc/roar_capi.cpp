@@ -488,6 +488,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
+    bool sets3 = false;
     if (mode == ROAR_VISITED_LDS) {
         // auto: 8192 tags (16 KB, 8 waves per CU) at short pools and for batches that do not fill the chip; 16384 tags
         // (32 KB, 4 waves per CU) once the pool is long enough for the small table to forget and there are queries
@@ -497,18 +498,29 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // 1 250 queries: the small table wins everywhere (profiles/r02_kernel_forms.txt).  L_pq = 60: 6.09 vs 7.26 ms.
         // With the hub bitmap the table holds the non-hub neighbours only: 8 192 tags below L_pq = 500, 4 096 beyond (LDS is
         // then better spent on resident waves: 1 250 queries at L_pq = 500, 5.19 ms with 4 096 tags, 6.90 ms with 8 192).
+        // Sparse graph, medium pools: 12 288 tags (3 x 1 024 sets) while five workgroups of that size fit a CU's LDS
+        // (L_pq <= 620) -- T2I-10M default graph, 8 192 -> 12 288 tags: 10 000 queries at L_pq = 300 / 400 / 500 15.90 -> 15.81 /
+        // 20.81 -> 20.58 / 25.76 -> 25.32 ms (cmps at 500: 21.4 k -> 20.4 k, reference 19.0 k), 1 250 queries 2.26 -> 2.18 /
+        // 2.94 -> 2.83 / 3.62 -> 3.45 ms; at L_pq = 200 and from 700 on (four per CU) the small table wins.
         uint32_t want = 8192u;
+        if (!use_hub && !dense && L >= 250 && L <= 620) want = 12288u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
         else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
         while ((1u << sets_log2) < sets) sets_log2++;
-        entries = 4u << sets_log2;
+        // 3 * 2^k sets (12 288, 24 576 ... tags) where that is what was asked for: the search kernel only
+        if (!bipartite && sets_log2 >= 2 && sets <= (3u << (sets_log2 - 2)) && (3u << (sets_log2 - 2)) >= min_sets) {
+            sets_log2 -= 2;
+            sets3 = true;
+        }
+        entries = (sets3 ? 12u : 4u) << sets_log2;
         if ((uint64_t)entries * 2 > 128 * 1024)
             return fail(ROAR_ERR_ARG, "visited table of %u entries does not fit in LDS", entries);
     }
     p.vis_sets_log2 = sets_log2;
+    p.vis_sets3 = sets3 ? 1u : 0u;
     uint32_t off = 0;
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
@@ -2142,7 +2154,11 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         if (value < 0 || value > 32) return fail(ROAR_ERR_ARG, "waves_per_cu must be 0..32");
         idx->waves_per_cu = (int)value;
     } else if (k == "vis_entries") {
-        if (value < 0 || (value & (value - 1))) return fail(ROAR_ERR_ARG, "vis_entries must be 0 or a power of two");
+        {
+            int64_t v = value;
+            while (v > 3 && !(v & 1)) v >>= 1;
+            if (value < 0 || (value > 0 && v != 1 && v != 2 && v != 3)) return fail(ROAR_ERR_ARG, "vis_entries must be 0, 2^k or 3 * 2^k");
+        }
         idx->vis_entries = (int)value;
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");

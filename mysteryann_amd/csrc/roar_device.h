@@ -30,6 +30,7 @@ struct RoarSearchParams {
     uint32_t *counter;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
     uint32_t vis_sets_log2;
+    uint32_t vis_sets3;  // 1: the table has 3 << vis_sets_log2 sets (search kernel only)
     // visited, EXACT mode: one u8[tag_stride] list per resident wave + its epoch
     uint8_t *tags;
     uint64_t tag_stride;

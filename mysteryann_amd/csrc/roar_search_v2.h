@@ -31,7 +31,7 @@ namespace {
 
 // LDS visited table, test-and-set of NC (1..3) ids per lane at once (one adjacency round trip; NC = the 64-word chunks
 // of the row that hold neighbours -- a row of at most 63 neighbours, the common case on a sparse graph, is one chunk).  Same table as
-// visited_filter<VIS_LDS> -- sets x 4 ways of u16 tags, (set, tag) <-> id a bijection, so a hit is never false -- but an
+// visited_filter<VIS_LDS> -- sets (2^k or 3 * 2^k) x 4 ways of u16 tags, (set, tag) <-> id a bijection, so a hit is never false -- but an
 // empty way is claimed with a 32-bit compare-and-swap on the half of the set that holds it: no write / barrier /
 // re-read round per insertion; a lane that loses a race sees the winner's word in the CAS result and tries the next
 // way.  The three probes of a lane are independent, so a round is written branch-free with the three atomics in
@@ -39,14 +39,20 @@ namespace {
 // scored again and its key is dropped by the merge as a duplicate or as worse than the pool's last entry).
 template <int NC>
 __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
-                                             uint32_t sets_log2, bool (&fresh)[NC]) {
+                                             uint32_t sets_log2, bool three, bool (&fresh)[NC]) {
     uint32_t *w[NC];
     uint32_t tag[NC], x[NC], y[NC];
     bool pend[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const uint32_t set = nb[c] & sets_mask;
-        tag[c] = (nb[c] >> sets_log2) + 1u;
+        uint32_t set = nb[c] & sets_mask;
+        uint32_t hi = nb[c] >> sets_log2;
+        if (three) {  // 3 << sets_log2 sets: set = id mod sets, tag = id div sets (exact division by 3 of a 32-bit value)
+            const uint32_t q3 = __umulhi(hi, 0xAAAAAAABu) >> 1;
+            set |= (hi - 3u * q3) << sets_log2;
+            hi = q3;
+        }
+        tag[c] = hi + 1u;
         w[c] = reinterpret_cast<uint32_t *>(vis + 4 * set);
     }
 #pragma unroll
@@ -300,7 +306,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
             *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
         if (MODE == VIS_LDS) {  // fresh visited table
-            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
+            const uint32_t n16 = ((p.vis_sets3 ? 12u : 4u) << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
             for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
         }
         if (HUB)
@@ -468,7 +474,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
                             }
                         } else {
-                            visited_ldsn<NC>(isn, nb, vis, sets_mask, p.vis_sets_log2, fresh);
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, p.vis_sets_log2, p.vis_sets3 != 0, fresh);
                         }
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {

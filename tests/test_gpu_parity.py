@@ -176,6 +176,37 @@ def test_high_degree_rows_and_large_pool(built_lib):
                 assert (r["cmps"] >= o["cmps"]).all()
 
 
+def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
+    """The on-chip table also comes in 3 * 2^k sets (12 288 tags is the default for medium pools on a sparse graph): set =
+    id mod sets, tag = id div sets must stay a bijection -- a hit may never be false.  Tiny tables (96, 192 tags: they forget
+    all the time), the default-sized one, and an id range that makes the quotient of the division by 3 non-trivial."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 50000, 24, 48
+    base, q, off, nbrs = _random_case(n, d, nq, 0, seed=9, maxdeg=40)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(3, off, nbrs)
+    idx.set_option("visited_mode", 1)
+    idx.set_option("hub_mode", 1)
+    for L in (40, 150, 400):
+        o = oracle.search_batch(base, off, nbrs, 3, q, K, L, 0)
+        for ve in (96, 192, 3072, 12288, 0):
+            idx.set_option("vis_entries", ve)
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            if ve:
+                assert idx.info("last_vis_entries") == ve
+            assert np.array_equal(r["ids"], o["ids"]), (L, ve)
+            assert np.array_equal(r["dists"], o["dists"]), (L, ve)
+            assert np.array_equal(r["hops"], o["hops"]), (L, ve)
+            assert (r["cmps"] >= o["cmps"]).all()
+    assert idx.info("last_vis_entries") == 12288  # L_pq = 400, average degree 20 x 96 B per row: a sparse graph
+    with pytest.raises(Exception):
+        idx.set_option("vis_entries", 5 * 1024)
+    idx.close()
+
+
 def test_forgetful_visited_table_keeps_results(built_lib):
     """A deliberately tiny LDS tag table forgets constantly: ids / dists / hops must not move,
     cmps may only grow."""

@@ -39,7 +39,7 @@ enum {
  *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
  *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
  *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the on-chip table up to L_pq ~ 1200-1500 (the switch point depends on the graph's density and on the hub form, csrc/roar_capi.cpp plan_search), HBM tags beyond */ };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the on-chip table up to L_pq ~ 500-1950 (the switch point depends on the graph's density and on the hub form, csrc/roar_capi.cpp plan_search), HBM tags beyond */ };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,

@@ -454,7 +454,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     //     36.85, 700 60.5 -> 49.6, 1 000 85.7 -> 68.5, 1 400 105.7 -> 91.3, 2 000 142.2 -> 128.6 ms; 1 250 queries:
     //     300 3.74 -> 3.28, 500 5.95 -> 5.19, 1 000 11.3 -> 9.31, 2 000 19.6 -> 17.5 ms.  The on-chip table (4 096 tags
     //     from L_pq = 500) then beats the HBM tags up to L_pq ~ 1 200 (1 000: 68.5 vs 74.1 ms; 1 400: 92.7 vs 91.3 ms).
-    //   sparse graph: the plain form with 8 192 tags up to L_pq = 1 500, HBM tags beyond.  T2I-10M reference-shaped
+    //   sparse graph: the plain form with 8 192 tags up to L_pq = 1 500 (4 096 to 1 950), HBM tags beyond.  T2I-10M reference-shaped
     //     graph, 10 000 queries, 8 192 tags / 4 096 tags + hub bitmap / 16 384 tags / HBM tags: L_pq = 100 6.17 / 6.14 /
     //     6.63 / 7.82 ms, 500 26.0 / 26.1 / 28.4 / 33.8, 1 000 55.0 / 55.6 / 74.8 / 63.9, 1 400 78.3 / 79.0 / 108.9 / 85.7,
     //     2 000 131.0 / 134.7 / 162.9 / 116.0 ms (profiles/r02_hub_forms*.txt).
@@ -475,7 +475,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (the two-hop walk touches an order of magnitude more distinct nodes per hop: the 8192-tag table forgets
     // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
     // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
-    const uint32_t lds_until = use_hub ? 1200u : dense ? 512u : 1500u;
+    // (sparse graph, L_pq 1 500 ... 1 900: a 4 096-tag table with six workgroups per CU re-scores 50 % more rows than the
+    // reference and still beats the HBM tags, 82.1 / 87.6 / 93.1 / 98.5 ms against 85.1 / 91.5 / 96.1 / 101.0 ms at L_pq = 1 500 /
+    // 1 600 / 1 700 / 1 800; at 2 000 the HBM tags win, 111.9 against 116.9 ms; scripts/long_pool_probe.py)
+    const uint32_t lds_until = use_hub ? 1200u : dense ? 512u : 1950u;
     const int mode = idx->visited_mode == ROAR_VISITED_AUTO
                          ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                          : idx->visited_mode;
@@ -499,11 +502,12 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // With the hub bitmap the table holds the non-hub neighbours only: 8 192 tags below L_pq = 500, 4 096 beyond (LDS is
         // then better spent on resident waves: 1 250 queries at L_pq = 500, 5.19 ms with 4 096 tags, 6.90 ms with 8 192).
         // Sparse graph, medium pools: 12 288 tags (3 x 1 024 sets) while five workgroups of that size fit a CU's LDS
-        // (L_pq <= 620) -- T2I-10M default graph, 8 192 -> 12 288 tags: 10 000 queries at L_pq = 300 / 400 / 500 15.90 -> 15.81 /
+        // (L_pq <= 530: 1 280-byte LDS blocks) -- T2I-10M default graph, 8 192 -> 12 288 tags: 10 000 queries at L_pq = 300 / 400 / 500 15.90 -> 15.81 /
         // 20.81 -> 20.58 / 25.76 -> 25.32 ms (cmps at 500: 21.4 k -> 20.4 k, reference 19.0 k), 1 250 queries 2.26 -> 2.18 /
         // 2.94 -> 2.83 / 3.62 -> 3.45 ms; at L_pq = 200 and from 700 on (four per CU) the small table wins.
         uint32_t want = 8192u;
-        if (!use_hub && !dense && L >= 250 && L <= 620) want = 12288u;
+        if (!use_hub && !dense && L >= 250 && L <= 530) want = 12288u;
+        if (!use_hub && !dense && L >= 1500) want = 4096u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
         else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
@@ -610,6 +614,14 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         if (e) return e;
     }
     idx->last_sel = sel;
+    // The LDS of a gfx950 CU is handed out in 1 280-byte blocks (160 KB / 128): a 32 128-byte workgroup takes 33 280 and
+    // four of them fit, not the five the occupancy query reports (measured: the 10 000-query launch at L_pq = 550 with
+    // 32 128 B ran at 4 per CU speed, 31 728 B at L_pq = 500 at 5 per CU speed).
+    {
+        const uint32_t alloc = round_up(std::max<uint32_t>(p.lds_bytes, 1u), 1280u);
+        const int by_lds = (int)((160u * 1024u) / alloc);  // workgroups per CU
+        if (by_lds >= 1 && occ > by_lds) occ = by_lds;
+    }
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
     // One-wave workgroups with the on-chip tag table: six per CU, not the eight the LDS allows -- the launch is bound by

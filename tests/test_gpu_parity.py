@@ -501,14 +501,14 @@ def test_exact_knn_query_block_larger_than_one_launch(built_lib):
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
     """Default policy (plan_search): a dense graph (average degree x row bytes >= 24 x 800) takes the hub-bitmap form from L_pq = 100 and
     the on-chip tag table below L_pq = 1200 (512 without the hub form), a sparse one the plain form with the table
-    below 1500; HBM epoch tags beyond.  All give the reference's results."""
+    below 1950; HBM epoch tags beyond.  All give the reference's results."""
     import oracle
     from mysteryann_amd import index as mi
 
     n, d, nq = 5000, 128, 20
     for maxdeg, plan in ((80, ((0, ((50, 1, 0), (99, 1, 0), (100, 1, 1), (1199, 1, 1), (1200, 0, 1), (1500, 0, 1))),
                                (1, ((50, 1, 0), (511, 1, 0), (512, 0, 0), (900, 0, 0))))),      # average degree ~ 39: dense
-                         (30, ((0, ((50, 1, 0), (300, 1, 0), (1499, 1, 0), (1500, 0, 0))),),)):  # ~ 14: sparse
+                         (30, ((0, ((50, 1, 0), (300, 1, 0), (1500, 1, 0), (1949, 1, 0), (1950, 0, 0))),),)):  # ~ 14: sparse
         base, q, off, nbrs = _random_case(n, d, nq, 0, seed=21, maxdeg=maxdeg)
         idx = mi.IndexBipartite(d, n, 0, None)
         idx.SetBaseData(base)

@@ -31,6 +31,9 @@ struct RoarSearchParams {
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
     uint32_t vis_sets_log2;
     uint32_t vis_sets3;  // 1: the table has 3 << vis_sets_log2 sets (search kernel only)
+    // host-buffer form with a pageable query block: rows [0, *ready) of `queries` (pinned staging) have been written by the
+    // host thread that is still packing the rest; null = every row is there (search kernel only)
+    const uint32_t *ready;
     // visited, EXACT mode: one u8[tag_stride] list per resident wave + its epoch
     uint8_t *tags;
     uint64_t tag_stride;

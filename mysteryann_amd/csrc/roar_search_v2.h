@@ -284,6 +284,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         if constexpr (W == 1) wave_sync();
         else lds_barrier();
     };
+    uint32_t ready_seen = 0;
 
     for (;;) {
         uint32_t q = 0;
@@ -296,6 +297,15 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             q = ctrl[0];
         }
         if (q >= p.nq) break;
+        if (p.ready && q >= ready_seen) {
+            // the host is still packing the query block behind this launch: wait until row q is there (the counter only
+            // grows, so a workgroup looks at it again only when it runs past what it has seen)
+            for (;;) {
+                ready_seen = __hip_atomic_load(p.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (ready_seen > q) break;
+                __builtin_amdgcn_s_sleep(100);
+            }
+        }
         long long tq0 = 0, t_adj = 0, t_filter = 0, t_score = 0, t_merge = 0, t_sel = 0;
         uint32_t pf_hit = 0, n_rt = 0, n_surv = 0;
         PassProf pprof;

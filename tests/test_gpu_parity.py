@@ -176,6 +176,44 @@ def test_high_degree_rows_and_large_pool(built_lib):
                 assert (r["cmps"] >= o["cmps"]).all()
 
 
+def test_pageable_query_block_is_packed_behind_the_launch(built_lib):
+    """A pageable host query block is copied into the library's pinned staging rows WHILE the kernel runs (the kernel
+    takes queries in row order and waits for the host's rows-written counter).  Many calls of every size, 800-byte rows
+    (not a multiple of the 128-byte line: staging rows are line-aligned for that reason) and padded dimensions: ids and
+    distances must equal the device-buffer call's, whatever the race between the packing thread and the launch."""
+    from mysteryann_amd import index as mi
+
+    rng = np.random.default_rng(3)
+    for d, metric, n in ((200, 1, 60000), (100, 0, 30000)):
+        base = rng.standard_normal((n, d)).astype(np.float32)
+        deg = rng.integers(8, 40, n)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum(deg)
+        nbrs = rng.integers(0, n, int(off[-1])).astype(np.uint32)
+        idx = mi.IndexBipartite(d, n, metric, None)
+        idx.SetBaseData(base)
+        idx.SetProjectionGraph(7, off, nbrs)
+        dpad = idx.info("dim_padded")
+        for it in range(120):
+            nq = int(rng.integers(1, 5000)) if it % 4 else int(rng.integers(1, 70))
+            q = rng.standard_normal((nq, d)).astype(np.float32)
+            idx.set_option("search_kernel", (0, 1, 3, 2)[it % 4] if nq <= 256 else 0)
+            r = idx.SearchRoarGraphBatch(q, 10, 30)
+            qd = torch_pad(q, dpad)
+            o = idx.SearchRoarGraphBatchDevice(qd, 10, 30)
+            assert np.array_equal(r["ids"].view(np.int32), o["ids"].cpu().numpy()), (d, it, nq)
+            assert np.array_equal(r["dists"], o["dists"].cpu().numpy()), (d, it, nq)
+        idx.close()
+
+
+def torch_pad(q, dpad):
+    import torch
+
+    t = torch.zeros((q.shape[0], dpad), dtype=torch.float32, device="cuda")
+    t[:, :q.shape[1]] = torch.from_numpy(q).cuda()
+    return t
+
+
 def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
     """The on-chip table also comes in 3 * 2^k sets (12 288 tags is the default for medium pools on a sparse graph): set =
     id mod sets, tag = id div sets must stay a bijection -- a hit may never be false.  Tiny tables (96, 192 tags: they forget

@@ -525,8 +525,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         if ((uint64_t)entries * 2 > 128 * 1024)
             return fail(ROAR_ERR_ARG, "visited table of %u entries does not fit in LDS", entries);
     }
-    p.vis_sets_log2 = sets_log2;
-    p.vis_sets3 = sets3 ? 1u : 0u;
+    p.vis_sets_log2 = sets_log2 | (sets3 ? 0x80000000u : 0u);
     uint32_t off = 0;
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
@@ -1496,7 +1495,12 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
     p.out_hops = hops_dev;
     p.out_scanned = scanned_dev;
     p.short_count = short_count_dev;
-    p.ready = ready_dev;
+    if (ready_dev) {  // (search_host asked gate_allowed() first)
+        if (plan.sel.form != ROAR_FORM_SEARCH || plan.sel.waves != 1 || plan.sel.hub || plan.sel.prof)
+            return fail(ROAR_ERR_ARG, "internal: this kernel form cannot wait for the packing thread");
+        p.ready = ready_dev;
+        plan.sel.gated = 1;
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
     if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
@@ -1619,6 +1623,16 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
     uint32_t qs = 0;
     bool deferred = false;
     if ((e = stage_queries(idx, queries, nq, qstride_floats, k, &qdev, &qs, &deferred))) return e;
+    if (deferred) {
+        // the kernel forms that can wait for the packing thread: one wave per query, no hub bitmap, not instrumented
+        LaunchPlan probe;
+        const bool gate = plan_search(idx, nq, k, L_pq, &probe) == ROAR_OK && probe.sel.form == ROAR_FORM_SEARCH &&
+                          probe.sel.waves == 1 && !probe.sel.hub && !probe.sel.prof;
+        if (!gate) {  // pack in front of the launch
+            pack_queries(idx, queries, nq, qstride_floats);
+            deferred = false;
+        }
+    }
     uint32_t *d_ids = idx->out_dev;
     float *d_dists = reinterpret_cast<float *>(d_ids + nq * k);
     uint32_t *d_cmps = d_ids + 2 * nq * k;

@@ -29,8 +29,7 @@ struct RoarSearchParams {
     // dynamic dequeue counter (zeroed before every launch)
     uint32_t *counter;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
-    uint32_t vis_sets_log2;
-    uint32_t vis_sets3;  // 1: the table has 3 << vis_sets_log2 sets (search kernel only)
+    uint32_t vis_sets_log2;  // bit 31 (search kernel only): the table has 3 << (value & 31) sets
     // host-buffer form with a pageable query block: rows [0, *ready) of `queries` (pinned staging) have been written by the
     // host thread that is still packing the rest; null = every row is there (search kernel only)
     const uint32_t *ready;
@@ -70,6 +69,7 @@ struct RoarKernelSel {
     int regpool;       // SEARCH / BUILDER: candidate pool in a register pair of wave 0 (L_pq <= 64) instead of LDS
     int prof;          // SEARCH: instrumented instantiation (phase timers; Text-to-Image shape only)
     int hub;           // SEARCH: hub-bitmap form (LDS pool only)
+    int gated;         // SEARCH, one wave per query, no hub / prof: queries become readable while the launch runs (RoarSearchParams::ready)
 };
 
 struct RoarDistParams {

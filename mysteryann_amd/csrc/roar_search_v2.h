@@ -256,7 +256,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ctrl words (LDS) of the multi-wave forms: 0 query, 1 candidates of the round trip (NONE = query finished),
 // 2 survivors appended by the waves, 3 pool full, 4-5 reject threshold (register-pool form)
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     extern __shared__ __align__(16) unsigned char smem[];
@@ -276,7 +276,9 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     const uint32_t *const ADJ = HUB ? p.adj_hub : p.adj;
     const uint32_t AS = HUB ? p.hub_stride : p.adj_stride;
     const uint32_t L = p.L;
-    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets
+    const bool sets3 = (p.vis_sets_log2 >> 31) != 0;
+    const uint32_t sets_mask = (1u << sets_log2) - 1u;
     const uint32_t NONE = 0xFFFFFFFFu;
     uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
     uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             q = ctrl[0];
         }
         if (q >= p.nq) break;
-        if (p.ready && q >= ready_seen) {
+        if (GATED && q >= ready_seen) {
             // the host is still packing the query block behind this launch: wait until row q is there (the counter only
             // grows, so a workgroup looks at it again only when it runs past what it has seen)
             for (;;) {
@@ -316,7 +318,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
             *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
         if (MODE == VIS_LDS) {  // fresh visited table
-            const uint32_t n16 = ((p.vis_sets3 ? 12u : 4u) << p.vis_sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
+            const uint32_t n16 = ((sets3 ? 12u : 4u) << sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
             for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
         }
         if (HUB)
@@ -484,7 +486,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
                             }
                         } else {
-                            visited_ldsn<NC>(isn, nb, vis, sets_mask, p.vis_sets_log2, p.vis_sets3 != 0, fresh);
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, fresh);
                         }
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
@@ -616,10 +618,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
 // Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of
 // a scoring pass for an occupancy the LDS footprint does not allow anyway).
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -639,6 +641,11 @@ const void *pick_form(const RoarKernelSel &s) {
                       : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
         else
             return nullptr;
+    }
+    if (s.gated) {  // one wave per query, waiting for the host's rows-written counter (pageable host query blocks)
+        if (s.hub || s.prof || s.waves != 1) return nullptr;
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, true>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, true>;
     }
     if (s.hub) {  // long pools: LDS pool, hub bitmap
         if (rp) return nullptr;

@@ -576,6 +576,19 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
         // results (:2408-2418); a short pool is reported, not thrown
         if (wid == 0) {
+            // The output pointers are used here only, once per query: they are read from the kernel-argument segment
+            // where they are used instead of living in (spilled) scalar registers through every hop.
+#if defined(__HIP_DEVICE_COMPILE__)
+            const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+            const RoarSearchParams *ka = &p;  // (host pass of the compiler: never executed)
+#endif
+            uint32_t *const o_ids = *const_cast<uint32_t *const volatile *>(&ka->out_ids);
+            float *const o_dists = *const_cast<float *const volatile *>(&ka->out_dists);
+            uint32_t *const o_cmps = *const_cast<uint32_t *const volatile *>(&ka->out_cmps);
+            uint32_t *const o_hops = *const_cast<uint32_t *const volatile *>(&ka->out_hops);
+            uint32_t *const o_scanned = *const_cast<uint32_t *const volatile *>(&ka->out_scanned);
+            uint32_t *const o_short = *const_cast<uint32_t *const volatile *>(&ka->short_count);
             for (uint32_t i = lane; i < p.k; i += 64) {
                 uint32_t id = 0xFFFFFFFFu;
                 float d = __builtin_inff();
@@ -584,14 +597,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     id = (uint32_t)e >> 1;
                     d = ord2f((uint32_t)(e >> 32));
                 }
-                p.out_ids[(u64)q * p.k + i] = id;
-                p.out_dists[(u64)q * p.k + i] = d;
+                o_ids[(u64)q * p.k + i] = id;
+                o_dists[(u64)q * p.k + i] = d;
             }
             if (lane == 0) {
-                if (p.out_cmps) p.out_cmps[q] = cmps;
-                if (p.out_hops) p.out_hops[q] = hops;
-                if (p.out_scanned) p.out_scanned[q] = scanned;
-                if (psize < p.k && p.short_count) atomicAdd(p.short_count, 1u);
+                if (o_cmps) o_cmps[q] = cmps;
+                if (o_hops) o_hops[q] = hops;
+                if (o_scanned) o_scanned[q] = scanned;
+                if (psize < p.k && o_short) atomicAdd(o_short, 1u);
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
                     o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);

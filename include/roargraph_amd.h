@@ -266,7 +266,7 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
  * here L_pq is an argument and the remaining knobs are integers:
  *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_AUTO (default AUTO)
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow, at most six
- *                    with the on-chip tag table)
+ *                    with the on-chip tag table and rows of 768 bytes or more)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |

@@ -629,7 +629,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // the memory system either way and the extra waves only add contention for it (T2I-10M default graph, 10 000 queries,
     // 5 / 6 / 7 / 8 per CU: L_pq = 55 3.585 / 3.593 / 3.603 / 3.635 ms, 100 6.09 / 5.98 / 6.03 / 6.11 ms; 2 500 queries at
     // L_pq = 55 0.973 / 0.997 / 0.970 / 1.021 ms).  EXACT mode wants every wave it can get (its tag probes are latency).
-    if (idx->waves_per_cu == 0 && mode == ROAR_VISITED_LDS && sel.waves == 1 && !bipartite && !idx->building) wpc = std::min(wpc, 6);
+    // Rows of 768 bytes and more only: with 512-byte rows (SIFT-1M shape, L_pq = 170, 28 fresh rows per hop) a wave has too
+    // little in flight and the seventh workgroup is worth 13 % (1.34 -> 1.51 M QPS).
+    if (idx->waves_per_cu == 0 && mode == ROAR_VISITED_LDS && sel.waves == 1 && !bipartite && !idx->building &&
+        idx->dim_pad * 4u >= 768u)
+        wpc = std::min(wpc, 6);
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
     if (grid > nq) grid = nq;
     if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;

@@ -239,7 +239,7 @@ def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
             assert np.array_equal(r["dists"], o["dists"]), (L, ve)
             assert np.array_equal(r["hops"], o["hops"]), (L, ve)
             assert (r["cmps"] >= o["cmps"]).all()
-    assert idx.info("last_vis_entries") == 12288  # L_pq = 400, average degree 20 x 96 B per row: a sparse graph
+    assert idx.info("last_vis_entries") == 4096  # auto at L_pq = 400 on a sparse graph with rows under 768 bytes: the small table (800-byte rows: 12 288)
     with pytest.raises(Exception):
         idx.set_option("vis_entries", 5 * 1024)
     idx.close()

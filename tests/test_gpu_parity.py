@@ -795,12 +795,20 @@ def test_pinned_query_block_is_read_in_place(golden_dir, built_lib):
     idx.close()
 
 
-def test_reference_builder_tracks_restated_reference_builder_at_200k(golden_dir, built_lib):
-    """SURVEY 8(f) #1 at a size where graph quality shows.  tests/golden/builder_yardstick_200000.json holds the degree
+def _yardsticks():
+    import glob
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(int(os.path.basename(f)[len("builder_yardstick_"):-len(".json")]) for f in glob.glob(os.path.join(d, "builder_yardstick_*.json")))
+
+
+@pytest.mark.parametrize("n_points", _yardsticks())
+def test_reference_builder_tracks_restated_reference_builder_at_scale(n_points, golden_dir, built_lib):
+    """SURVEY 8(f) #1 at sizes where graph quality shows.  tests/golden/builder_yardstick_<n>.json holds the degree
     statistics and the recall@10 / distance-evaluation curve of the CPU restatement of the reference's BuildRoarGraph
-    (oracle/roar_builder_oracle.c, 23 minutes single-threaded; tests/scale/builder_yardstick.py) on a seeded 200 000-point
-    T2I-shape set with the canonical parameters.  roar_build_roargraph_device on the same data and the same exact lists
-    must track it: entry point equal, average degree within 3 %, longest row equal, recall within 0.005 and distance
+    (oracle/roar_builder_oracle.c, single-threaded: 23 minutes at 200 000 points; tests/scale/builder_yardstick.py) on a
+    seeded T2I-shape set with the canonical parameters.  roar_build_roargraph_device on the same data and the same exact
+    lists must track it: entry point equal, average degree within 3 %, longest row equal, recall within 0.005 and distance
     evaluations within 5 % at L_pq = 20 / 50 / 100 (the reference builder itself is order-dependent, so bytes cannot be
     compared)."""
     import json
@@ -809,7 +817,7 @@ def test_reference_builder_tracks_restated_reference_builder_at_200k(golden_dir,
 
     from mysteryann_amd import index as mi, synth
 
-    Y = json.load(open(os.path.join(golden_dir, "builder_yardstick_200000.json")))
+    Y = json.load(open(os.path.join(golden_dir, f"builder_yardstick_{n_points}.json")))
     n, nq = Y["n"], Y["nq"]
     base, q, learn = synth.t2i_numpy(n, nq, 200, seed=Y["seed"], n_learn=Y["n_learn"])
     idx = mi.IndexBipartite(200, n, mi.INNER_PRODUCT, None)

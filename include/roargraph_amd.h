@@ -188,7 +188,9 @@ int roar_search_batch_multi(roar_index *const *replicas, uint32_t g, const float
 /* Pinned, device-mapped host memory for query blocks (what load_data / data_align of the facade header return):
  * roar_search_batch reads a query block that lives in such memory in place -- no staging copy, no host-to-device
  * copy in front of the kernel -- when its rows are strided at >= the padded dimension and the dimension needs no
- * padding; any other host pointer works too and is packed into an internal pinned block first.  NULL on failure. */
+ * padding; any other host pointer works too: its rows are copied into an internal pinned block by the calling thread
+ * WHILE the kernel already runs (the kernel takes queries in row order and waits for the rows-written counter), so the
+ * block must stay valid and unchanged until the call returns, as for any argument.  NULL on failure. */
 void *roar_host_alloc(uint64_t bytes);
 void roar_host_free(void *p);
 

@@ -20,8 +20,30 @@ args = ap.parse_args()
 n = args.n
 t0 = time.time()
 base, q, learn = synth.t2i_numpy(n, args.nq, 200, seed=args.seed, n_learn=n)
-knn, _ = exact_knn(learn, base, 100, 1)
-gt, _ = exact_knn(q, base, 10, 1)
+
+
+def exact_knn_big(Q, X, k, chunk=1024):
+    """Inner-product top-k by torch on the host cores (multi-threaded matmul + topk), ordered by (distance, id): the numpy
+    argpartition of tests/golden/small_builder.py needs hours at a million points."""
+    import torch
+
+    Xt = torch.from_numpy(X)
+    ids = np.zeros((Q.shape[0], k), np.uint32)
+    for i in range(0, Q.shape[0], chunk):
+        d = -(torch.from_numpy(Q[i:i + chunk]) @ Xt.T)
+        v, j = torch.topk(d, k, dim=1, largest=False, sorted=True)
+        v, j = v.numpy(), j.numpy()
+        order = np.lexsort((j, v), axis=1)
+        ids[i:i + chunk] = np.take_along_axis(j, order, 1)
+    return ids
+
+
+if n > 300_000:
+    knn = exact_knn_big(learn, base, 100)
+    gt = exact_knn_big(q, base, 10)
+else:
+    knn, _ = exact_knn(learn, base, 100, 1)
+    gt, _ = exact_knn(q, base, 10, 1)
 print(f"data + exact lists in {time.time() - t0:.0f}s", flush=True)
 t0 = time.time()
 ep, off, nbrs = oracle.build_roargraph(base, knn, 1, 100, 35, 500)

@@ -806,10 +806,12 @@ def _yardsticks():
 def test_reference_builder_tracks_restated_reference_builder_at_scale(n_points, golden_dir, built_lib):
     """SURVEY 8(f) #1 at sizes where graph quality shows.  tests/golden/builder_yardstick_<n>.json holds the degree
     statistics and the recall@10 / distance-evaluation curve of the CPU restatement of the reference's BuildRoarGraph
-    (oracle/roar_builder_oracle.c, single-threaded: 23 minutes at 200 000 points; tests/scale/builder_yardstick.py) on a
+    (oracle/roar_builder_oracle.c, single-threaded: 23 minutes at 200 000 points, 2 h 46 min at 1 000 000;
+    tests/scale/builder_yardstick.py) on a
     seeded T2I-shape set with the canonical parameters.  roar_build_roargraph_device on the same data and the same exact
-    lists must track it: entry point equal, average degree within 3 %, longest row equal, recall within 0.005 and distance
-    evaluations within 5 % at L_pq = 20 / 50 / 100 (the reference builder itself is order-dependent, so bytes cannot be
+    lists must track it: entry point equal, average degree within 3 %, longest row equal, recall within 0.005 (or three
+    standard deviations of the 1 000-query estimate, 0.012 at a recall of 0.8) and distance evaluations within 5 % at L_pq =
+    20 / 50 / 100 (the reference builder itself is order-dependent, so bytes cannot be
     compared)."""
     import json
 
@@ -837,7 +839,9 @@ def test_reference_builder_tracks_restated_reference_builder_at_scale(n_points, 
         r = idx.SearchRoarGraphBatch(q, 10, L)
         rec = mi.ComputeRecall(r["ids"], gt, 10)
         want = Y["curve"][str(L)]
-        assert abs(rec - want["recall_at_10"]) <= 0.005, (L, rec, want)
+        # (two different graphs evaluated on nq queries: three standard deviations of a recall of that size, at least 0.005)
+        tol = max(0.005, 3.0 * (want["recall_at_10"] * (1.0 - want["recall_at_10"]) / (nq * 10)) ** 0.5)
+        assert abs(rec - want["recall_at_10"]) <= tol, (L, rec, want, tol)
         assert abs(r["cmps"].mean() - want["avg_cmps"]) <= 0.05 * want["avg_cmps"], (L, r["cmps"].mean(), want)
     idx.close()
 

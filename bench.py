@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- QPS @ recall@10 >= 0.9 on the Text-to-Image-10M shape (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: either launched by torch.distributed.run, one rank per
+                                                          GPU, or typed as is -- it then starts those ranks itself as a
+                                                          child process, before anything here touches the GPU)
 
 One "step" = one pass of the hot path (the batched RoarGraph beam search, one kernel launch per GPU) over ONE
 10 000-query OOD batch, inputs already resident in HBM.  Workload (config.workload "t2i-10M-ip"): synthetic
@@ -72,7 +74,37 @@ def recall_at_k(torch, ids, gt, k):
     return hit / float(k * ids.shape[0])
 
 
-def main():
+def free_port():
+    """A TCP port nobody listens on right now (for the rendezvous of a self-started N > 1 run)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launcher_command(argv, gpus, port):
+    """Command line that runs this script as `gpus` ranks of one node, one per GPU, over RCCL -- what the driver types
+    for N > 1.  argv = this process's own arguments (sys.argv[1:]), passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` typed as a plain command with N > 1: start the N ranks as a CHILD process and hand its
+    exit code back.  This runs before torch is imported, i.e. before anything in this process has touched the GPU (a
+    process that has must never be replaced by exec; a child is always fine).  -> exit code, or None to go on here."""
+    if args.gpus <= 1 or "RANK" in os.environ or args.pmc_child:
+        return None
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = launcher_command(argv, args.gpus, free_port())
+    log("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
@@ -145,7 +177,14 @@ def main():
     ap.add_argument("--sharded", action="store_true",
                     help="BASELINE configs[4]: the base set split over the ranks (12.5 M points each by default, own graph "
                          "per shard), every rank searches all queries, RCCL all-gather of the per-shard top-k, HIP merge")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    rc = self_launch(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
 
     import numpy as np
     import torch
@@ -159,11 +198,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
-    torch.cuda.set_device(local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+    if args.gpus != world:  # (a plain `python bench.py --gpus N` never gets here: self_launch() started the ranks)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: the launcher's --nproc-per-node and --gpus must agree")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s)")
+    torch.cuda.set_device(local)
     if use_dist:
         import torch.distributed as dist
 

@@ -116,6 +116,10 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=8,
                     help="distinct query batches rotated through the timed loop (same distribution, own draws), so that a "
                          "step never finds the rows of the step before it in the Infinity Cache")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="launches in flight in the timed loop (step s on stream s mod IN_FLIGHT; each step its own batch and result "
+                         "buffers).  1 = one launch after the other.  The kernel's own duration (roofline) is always measured "
+                         "one launch at a time")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = ONE nq-query batch per step, rank r searches rows [r nq/N, (r+1) nq/N) of it "
                          "(BASELINE configs[3]); weak = every rank searches its own nq-query batch")
@@ -311,8 +315,8 @@ def main():
     if args.vis_entries:
         idx.set_option("vis_entries", args.vis_entries)
 
-    def run(L, b=0, out=None):
-        return idx.SearchRoarGraphBatchDevice(batches[b], args.k, L, out=out)
+    def run(L, b=0, out=None, stream=None):
+        return idx.SearchRoarGraphBatchDevice(batches[b], args.k, L, out=out, stream=stream)
 
     def global_recall(ids, gt):
         """recall@k over the whole batch: hits of this rank's rows, summed over the ranks"""
@@ -384,20 +388,33 @@ def main():
         outs.append(o)
     rec = float(np.mean(recalls))
 
-    def timed(order):
-        """`steps` launches, batch of step s = order(s); barrier + synchronize on both sides; -> (wall s max over ranks, gpu ms)"""
+    main_stream = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(dev) for _ in range(max(1, min(args.in_flight, B)))]
+
+    def timed(order, in_flight=1):
+        """`steps` launches, batch of step s = order(s); barrier + synchronize on both sides; -> (wall s max over ranks, gpu ms).
+        in_flight > 1: step s is launched on stream s mod in_flight, so that a step's last queries (a launch ends with its
+        slowest query: 72 hops against 61 on average) run beside the next step's first ones; every step still searches its
+        own whole batch into its own result buffers inside the timed region."""
+        streams = [main_stream] if in_flight <= 1 else side[:in_flight]
         for s_ in range(args.warmup):
-            run(chosen, order(s_), outs[order(s_)])
+            run(chosen, order(s_), outs[order(s_)], streams[s_ % len(streams)])
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_ = time.perf_counter()
-        e0.record()
+        e0.record(main_stream)
+        for st_ in streams:
+            if st_ is not main_stream:
+                st_.wait_event(e0)
         for s_ in range(args.steps):
-            run(chosen, order(s_), outs[order(s_)])
-        e1.record()
+            run(chosen, order(s_), outs[order(s_)], streams[s_ % len(streams)])
+        for st_ in streams:
+            if st_ is not main_stream:
+                main_stream.wait_stream(st_)
+        e1.record(main_stream)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -410,11 +427,16 @@ def main():
         return wall_, e0.elapsed_time(e1)  # events on the launch stream (torch's current stream is passed down)
 
     wall_replay, gpu_replay = timed(lambda s_: 0)           # the same batch every step (rows of the last step still cached)
-    wall, gpu_ms = timed(lambda s_: s_ % B)                 # distinct batches in rotation: THE measurement
-    last_kernel_ms = idx.info("last_kernel_ns") * 1e-6
+    wall_serial, gpu_ms = timed(lambda s_: s_ % B)          # distinct batches in rotation, one launch after the other:
+    last_kernel_ms = idx.info("last_kernel_ns") * 1e-6      #   the kernel's own duration (roofline) comes from this loop
+    kernel_ms = gpu_ms / args.steps
+    depth = len(side)
+    if depth > 1:                                           # THE measurement: the same K steps, `depth` launches in flight
+        wall, gpu_pipe = timed(lambda s_: s_ % B, depth)
+    else:
+        wall, gpu_pipe = wall_serial, gpu_ms
     ms_per_step = wall * 1e3 / args.steps
     qps = total_q * args.steps / wall
-    kernel_ms = gpu_ms / args.steps
     bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
@@ -438,6 +460,8 @@ def main():
                    "n_queries_per_gpu": mine, "k": args.k, "L_pq": chosen, "recall_at_10": rec,
                    "recall_at_10_min_over_batches": float(min(recalls)),
                    "query_batches_rotated": B, "ms_per_step_same_batch_replayed": wall_replay * 1e3 / args.steps,
+                   "launches_in_flight": depth, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
+                   "value_one_launch_at_a_time": total_q * args.steps / wall_serial,
                    "parallelism": (f"index replicated on {world} GPU(s); one {args.nq}-query batch per step split by query, "
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),

@@ -263,6 +263,39 @@ int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
 int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
                            const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream);
 
+/* local ids of one shard -> global ids: ids_dev[i] += base for every entry that is a result (0xFFFFFFFF = "no result" is
+ * kept).  Device buffer, asynchronous on `hip_stream`. */
+int roar_rebase_ids_device(int device, uint32_t *ids_dev, uint64_t count, uint32_t base, void *hip_stream);
+
+/* ---- index-sharded search (BASELINE configs[4]: the base set exceeds one GPU) -------------
+ * Not in the reference, whose one index lives in one address space; this is what its harness loop
+ * (tests/test_search_roargraph.cpp:202-209) calls when the base rows are cut into contiguous id ranges, one RoarGraph per
+ * range (local ids, own entry point).  One process drives all devices:
+ *   roar_sharded_create     n_shards (<= 32) empty shard indexes, shard s on HIP device devices[s] (a device may hold
+ *                           several shards; ranks = distinct devices, and ranks x shards-per-rank <= 32)
+ *   roar_sharded_shard      the roar_index of shard s -- load its base rows and its graph with the ordinary calls
+ *                           (roar_load_base_fbin / roar_set_base*, roar_load_graph_file / roar_build_roargraph ...); owned
+ *                           by the roar_sharded
+ *   roar_sharded_set_id_base  global id of shard s's row 0 (default: the running sum of the shard sizes)
+ *   roar_search_batch_sharded  every query on every shard with the same L_pq (one host thread + one stream per device,
+ *                           shards of a device back to back), local ids rebased to global ids, then the ONE exchange
+ *                           step of the path -- ncclAllGather (RCCL over xGMI; ncclCommInitAll on first use) of every
+ *                           rank's [shard][nq][k] ids and distances, nq x k x 8 bytes per shard -- and the k-way merge by
+ *                           (distance, id) on every rank (roar_merge_topk_device); rank 0's lists return in the caller's
+ *                           HOST arrays ids[nq][k] (global ids), dists[nq][k]; cmps / hops (may be NULL) are the query's
+ *                           distance evaluations / expansions summed over the shards.  Errors as roar_search_batch;
+ *                           ROAR_ERR_SHORT only if all shards together returned fewer than k results for some query.
+ *   roar_sharded_info       "shards", "ranks", "last_search_ns" (slowest rank: query upload + its shards' searches),
+ *                           "last_exchange_ns" (slowest rank: all-gather + merge), both by HIP events of the last call */
+typedef struct roar_sharded roar_sharded;
+int roar_sharded_create(roar_sharded **out, uint32_t dim, int metric, const int *devices, uint32_t n_shards);
+void roar_sharded_destroy(roar_sharded *sh);
+roar_index *roar_sharded_shard(roar_sharded *sh, uint32_t s);
+int roar_sharded_set_id_base(roar_sharded *sh, uint32_t s, uint64_t first_global_id);
+int roar_search_batch_sharded(roar_sharded *sh, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                              uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops);
+int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
+
 /* ---- options / introspection ----------------------------------------------------------------
  * Parameters::Set / Get  include/efanna2e/parameters.h:15-57 carry L_pq per call in the reference;
  * here L_pq is an argument and the remaining knobs are integers:

@@ -26,6 +26,8 @@ SYMBOLS = [
     "roar_build_bipartite", "roar_bipartite_entry_ids", "roar_search_bipartite_batch",
     "roar_search_bipartite_batch_device", "roar_last_profile", "roar_clone_to_device", "roar_search_batch_multi",
     "roar_host_alloc", "roar_host_free", "roar_queue_trace", "roar_build_roargraph_device",
+    "roar_rebase_ids_device", "roar_sharded_create", "roar_sharded_destroy", "roar_sharded_shard",
+    "roar_sharded_set_id_base", "roar_search_batch_sharded", "roar_sharded_info",
 ]
 
 
@@ -123,8 +125,18 @@ def lib():
                                               u32p, fp, u32p, u32p]
     l.roar_search_bipartite_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    l.roar_rebase_ids_device.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
+    l.roar_sharded_create.argtypes = [C.POINTER(vp), C.c_uint32, C.c_int, C.POINTER(C.c_int), C.c_uint32]
+    l.roar_sharded_destroy.argtypes = [vp]
+    l.roar_sharded_destroy.restype = None
+    l.roar_sharded_shard.argtypes = [vp, C.c_uint32]
+    l.roar_sharded_shard.restype = vp
+    l.roar_sharded_set_id_base.argtypes = [vp, C.c_uint32, C.c_uint64]
+    l.roar_search_batch_sharded.argtypes = [vp, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, u32p]
+    l.roar_sharded_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     for s in SYMBOLS:
-        if s not in ("roar_destroy", "roar_last_error", "roar_host_alloc", "roar_host_free"):
+        if s not in ("roar_destroy", "roar_last_error", "roar_host_alloc", "roar_host_free", "roar_sharded_destroy",
+                     "roar_sharded_shard"):
             getattr(l, s).restype = C.c_int
     _lib = l
     return l

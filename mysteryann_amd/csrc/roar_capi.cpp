@@ -152,13 +152,19 @@ struct roar_index {
     bool building = false;  // searches issued by roar_build_graph run under their own kernel symbol
     RoarKernelSel last_sel = {};
     // workspaces
-    uint32_t *counters = nullptr;  // [0] dequeue counter, [1] short count
+    uint32_t *counters = nullptr;  // two-hop kernels: [0] dequeue counter (zeroed before every launch)
+    // SearchRoarGraph launches: a ring of 16-byte launch cells (RoarSearchParams::counter), zero between launches -- the
+    // kernel cleans up after itself, so launches on different streams may overlap and nothing is queued in front of one
+    uint32_t *ring = nullptr;
+    std::atomic<uint32_t> launch_seq{0};
     uint8_t *tags = nullptr;
     uint32_t *epochs = nullptr;
     uint32_t slots = 0;
     uint64_t tag_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    hipStream_t last_stream = nullptr;  // stream of the most recent search launch, and whether it used the HBM tag lists
+    bool last_used_tags = false;
     // host-API staging: queries are packed into pinned host memory that the kernel reads in place (no H2D step),
     // results come back through a pinned block with one asynchronous copy; everything on the index's own stream
     hipStream_t stream = nullptr;
@@ -341,6 +347,7 @@ int ensure_host_csr(roar_index *idx) {
     return ROAR_OK;
 }
 
+constexpr uint32_t LAUNCH_RING = 256;  // launch cells: more launches than this are never in flight on one index
 constexpr size_t ADJ_SLACK_WORDS = 256;  // a row read is up to 4 x 64 words from the row's first word
 
 // Hub-annotated adjacency (see RoarSearchParams::adj_hub).  Host pass over the device rows, once per graph: in-degrees,
@@ -784,6 +791,14 @@ extern "C" {
 
 const char *roar_last_error(void) { return g_err.c_str(); }
 
+// (internal, for the library's other translation units: roar_sharded.cpp)
+void roar_set_last_error(const char *msg) {
+    try {
+        g_err = msg ? msg : "";
+    } catch (...) {
+    }
+}
+
 int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
     if (!out) return fail(ROAR_ERR_ARG, "null output pointer");
     *out = nullptr;
@@ -810,6 +825,8 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         idx->n_cus = prop.multiProcessorCount;
         HIP_TRY(hipMalloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&idx->ring, LAUNCH_RING * 4 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(idx->ring, 0, LAUNCH_RING * 4 * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&idx->ev0));
         HIP_TRY(hipEventCreate(&idx->ev1));
@@ -835,6 +852,7 @@ void roar_destroy(roar_index *idx) {
     free_tags(idx);
     if (idx->init_dev) (void)hipFree(idx->init_dev);
     if (idx->counters) (void)hipFree(idx->counters);
+    if (idx->ring) (void)hipFree(idx->ring);
     if (idx->q_pin) (void)hipHostFree(idx->q_pin);
     if (idx->ready_pin) (void)hipHostFree(idx->ready_pin);
     if (idx->out_dev) (void)hipFree(idx->out_dev);
@@ -1510,8 +1528,14 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
         plan.sel.gated = 1;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    HIP_TRY(hipMemsetAsync(idx->counters, 0, 2 * sizeof(uint32_t), st));
-    if (short_count_dev) HIP_TRY(hipMemsetAsync(short_count_dev, 0, sizeof(uint32_t), st));
+    p.counter = idx->ring + 4 * (size_t)(idx->launch_seq.fetch_add(1) % LAUNCH_RING);
+    // Launches of one index on different streams may overlap (each has its own launch cell) -- except where they would
+    // share per-workgroup state in HBM: the EXACT-mode tag lists / the spill lists are indexed by workgroup, so such a
+    // launch waits for the previous one.
+    if (idx->ev_valid && idx->last_stream != st && (plan.sel.visited_mode == ROAR_VISITED_EXACT || idx->last_used_tags))
+        HIP_TRY(hipStreamWaitEvent(st, idx->ev1, 0));
+    idx->last_stream = st;
+    idx->last_used_tags = plan.sel.visited_mode == ROAR_VISITED_EXACT;
     HIP_TRY(hipEventRecord(idx->ev0, st));
     int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2176,6 +2200,17 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
     HIP_TRY(hipSetDevice(device));
     int rc = roar_launch_merge_topk(nshards, nq, k, ids_dev, dists_dev, out_ids_dev, out_dists_dev, hip_stream);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "merge kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return ROAR_OK;
+}
+
+int roar_rebase_ids_device(int device, uint32_t *ids_dev, uint64_t count, uint32_t base, void *hip_stream) {
+    if (!ids_dev && count) return fail(ROAR_ERR_ARG, "bad rebase arguments");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0)
+        return fail(ROAR_ERR_DEVICE, "no HIP device available; this library has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    int rc = roar_launch_rebase_ids(ids_dev, count, base, hip_stream);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "rebase kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return ROAR_OK;
 }
 

@@ -26,7 +26,9 @@ struct RoarSearchParams {
     uint32_t *out_hops;
     uint32_t *out_scanned;
     uint32_t *short_count;
-    // dynamic dequeue counter (zeroed before every launch)
+    // launch cell, u32[4] = {next query to dequeue, workgroups that have left, short queries, -}.  SearchRoarGraph
+    // kernels: zero on entry, zeroed again by the last workgroup to leave (which also stores the short count to
+    // *short_count).  Two-hop kernels: word 0 only, zeroed by the host before every launch.
     uint32_t *counter;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
     uint32_t vis_sets_log2;  // bit 31 (search kernel only): the table has 3 << (value & 31) sets
@@ -93,6 +95,7 @@ int roar_launch_search(const RoarSearchParams *p, const RoarKernelSel *sel, uint
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
+int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
 // Max resident workgroups per CU for the selected kernel at this LDS size.
 int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
 #ifdef __cplusplus

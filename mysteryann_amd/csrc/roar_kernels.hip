@@ -403,6 +403,12 @@ __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams 
     }
 }
 
+// local ids of a shard -> global ids (index-sharded configuration); "no result" stays "no result"
+__global__ void roar_rebase_ids_kernel(uint32_t *__restrict__ ids, u64 count, uint32_t base) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && ids[i] != 0xFFFFFFFFu) ids[i] += base;
+}
+
 // k-way merge of per-shard sorted top-k lists by (distance, id); one thread per query.
 __global__ void roar_merge_topk_kernel(uint32_t nshards, u64 nq, uint32_t k, const uint32_t *__restrict__ ids,
                                        const float *__restrict__ dists, uint32_t *__restrict__ out_ids,
@@ -583,6 +589,12 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
         hipLaunchKernelGGL(roar_distance_kernel<true>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
     else
         hipLaunchKernelGGL(roar_distance_kernel<false>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream) {
+    if (count == 0 || base == 0) return 0;
+    hipLaunchKernelGGL(roar_rebase_ids_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, (u64)count, base);
     return (int)hipGetLastError();
 }
 

@@ -588,7 +588,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             uint32_t *const o_cmps = *const_cast<uint32_t *const volatile *>(&ka->out_cmps);
             uint32_t *const o_hops = *const_cast<uint32_t *const volatile *>(&ka->out_hops);
             uint32_t *const o_scanned = *const_cast<uint32_t *const volatile *>(&ka->out_scanned);
-            uint32_t *const o_short = *const_cast<uint32_t *const volatile *>(&ka->short_count);
             for (uint32_t i = lane; i < p.k; i += 64) {
                 uint32_t id = 0xFFFFFFFFu;
                 float d = __builtin_inff();
@@ -604,7 +603,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 if (o_cmps) o_cmps[q] = cmps;
                 if (o_hops) o_hops[q] = hops;
                 if (o_scanned) o_scanned[q] = scanned;
-                if (psize < p.k && o_short) atomicAdd(o_short, 1u);
+                if (psize < p.k) atomicAdd(p.counter + 2, 1u);  // short queries of this launch (handed over at the end)
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
                     o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);
@@ -627,6 +626,20 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         block_sync();
     }
     if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
+    // Launch slot {next query, workgroups done, short queries, -} (one 16-byte cell of the index's ring): the last
+    // workgroup to leave hands the short count to the caller and leaves the cell zeroed for the launch that takes it
+    // next, so no memset is queued in front of a launch.  (This workgroup's dequeue and short-count atomics were
+    // issued before the one below, to the same L2 channel.)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(p.counter + 1, 1u) == gridDim.x - 1u) {
+            const uint32_t nshort = atomicExch(p.counter + 2, 0u);
+            if (p.short_count) *p.short_count = nshort;
+            atomicExch(p.counter + 1, 0u);
+            __threadfence();
+            atomicExch(p.counter, 0u);
+        }
+    }
 }
 
 // Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of

@@ -378,6 +378,67 @@ class IndexBipartite:
         return out
 
 
+class ShardedIndex:
+    """The index-sharded configuration (roar_sharded_*): shard s is an IndexBipartite over its own
+    rows (local ids) on device devices[s]; Search runs every query on every shard and merges the per-shard lists after one
+    RCCL all-gather.  shard(s) returns a non-owning IndexBipartite view: load its base rows and graph as usual."""
+
+    def __init__(self, dimension, metric, devices):
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        capi.check(self._lib.roar_sharded_create(C.byref(self._h), int(dimension), int(metric), devs, len(devices)))
+        self.dimension, self.metric, self.devices = int(dimension), int(metric), [int(d) for d in devices]
+        self._views = {}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            for v in self._views.values():
+                v._h = C.c_void_p()  # owned by the roar_sharded
+            self._lib.roar_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, s):
+        if s not in self._views:
+            h = self._lib.roar_sharded_shard(self._h, int(s))
+            if not h:
+                raise RoarError(capi.ERR_ARG, self._lib.roar_last_error().decode())
+            v = IndexBipartite.__new__(IndexBipartite)
+            v._lib, v._h = self._lib, C.c_void_p(h)
+            v.dimension, v.metric, v.device = self.dimension, self.metric, self.devices[s]
+            v.need_normalize = self.metric == COSINE
+            v._keep = []
+            v.close = lambda: None  # non-owning
+            self._views[s] = v
+        return self._views[s]
+
+    def set_id_base(self, s, first_global_id):
+        capi.check(self._lib.roar_sharded_set_id_base(self._h, int(s), int(first_global_id)))
+
+    def info(self, key):
+        v = C.c_int64()
+        capi.check(self._lib.roar_sharded_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def SearchRoarGraphBatch(self, queries, k, L_pq):
+        """-> dict(ids [nq, k] global ids, dists, cmps, hops (summed over the shards)); host buffers."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        nq, qs = queries.shape
+        ids = np.zeros((nq, k), np.uint32)
+        dists = np.zeros((nq, k), np.float32)
+        cmps = np.zeros(nq, np.uint32)
+        hops = np.zeros(nq, np.uint32)
+        capi.check(self._lib.roar_search_batch_sharded(self._h, capi.f32p(queries), nq, qs, int(k), int(L_pq), capi.u32p(ids),
+                                                       capi.f32p(dists), capi.u32p(cmps), capi.u32p(hops)))
+        return dict(ids=ids, dists=dists, cmps=cmps, hops=hops)
+
+
 def ComputeRecall(res, gt, k):
     """tests/test_search_roargraph.cpp:23-36: |gt[:k] in res[:k]| / (k * nq)."""
     res = np.asarray(res)[:, :k].astype(np.int64)

@@ -437,6 +437,70 @@ def test_index_sharded_search_equals_merge_of_per_shard_cpu_searches(built_lib):
     assert np.array_equal(md_.cpu().numpy(), want_d)
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_c_abi_sharded_search_with_rccl_equals_merge_of_per_shard_cpu_searches(built_lib, devices):
+    """BASELINE configs[4] through the C ABI (roar_sharded_*, row E2b): shards placed on device 0 form one RCCL rank --
+    ncclCommInitAll + ncclAllGather really run -- and the merged global lists equal the merge of the oracle's per-shard
+    searches; shard sizes are ragged, cmps / hops are the sums over the shards."""
+    import oracle
+    from mysteryann_amd import index as mi
+    from mysteryann_amd import parallel
+
+    S = len(devices)
+    n, d, nq, L = 6001, 200, 53, 40
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    sh = mi.ShardedIndex(d, mi.INNER_PRODUCT, devices)
+    assert sh.info("shards") == S and sh.info("ranks") == 1
+    oi, od, oc, oh = [], [], 0, 0
+    for s in range(S):
+        lo, hi = parallel.shard_range(n, S, s)
+        m = hi - lo
+        srng = np.random.default_rng(50 + s)
+        deg = srng.integers(3, 30, m)
+        off = np.zeros(m + 1, np.uint64)
+        off[1:] = np.cumsum(deg)
+        nbrs = srng.integers(0, m, int(off[-1])).astype(np.uint32)
+        idx = sh.shard(s)
+        idx.SetBaseData(base[lo:hi])
+        idx.SetProjectionGraph(1, off, nbrs)
+        idx.set_option("visited_mode", 0)  # cmps as the reference counts them
+        o = oracle.search_batch(base[lo:hi], off, nbrs, 1, q, K, L, 1)
+        oi.append(o["ids"] + np.uint32(lo))
+        od.append(o["dists"])
+        oc, oh = oc + o["cmps"].astype(np.int64), oh + o["hops"].astype(np.int64)
+    for _ in range(2):  # the second call reuses communicators and buffers
+        r = sh.SearchRoarGraphBatch(q, K, L)
+    want_i = np.zeros((nq, K), np.uint32)
+    want_d = np.zeros((nq, K), np.float32)
+    for qi in range(nq):
+        ci = np.concatenate([x[qi] for x in oi])
+        cd = np.concatenate([x[qi] for x in od])
+        o = np.lexsort((ci, cd))[:K]
+        want_i[qi], want_d[qi] = ci[o], cd[o]
+    assert np.array_equal(r["ids"], want_i)
+    assert np.array_equal(r["dists"], want_d)
+    assert np.array_equal(r["cmps"], oc) and np.array_equal(r["hops"], oh)
+    assert sh.info("last_search_ns") > 0 and sh.info("last_exchange_ns") > 0
+    with pytest.raises(mi.RoarError):
+        sh.SearchRoarGraphBatch(q, 10, 5)  # L_pq < k, as the harness refuses it (tests/test_search_roargraph.cpp:192-195)
+    sh.close()
+
+
+def test_c_abi_sharded_refuses_bad_placements(built_lib):
+    from mysteryann_amd import index as mi
+
+    with pytest.raises(mi.RoarError):
+        mi.ShardedIndex(200, mi.INNER_PRODUCT, [0, 4096])  # no such device
+    with pytest.raises(mi.RoarError):
+        mi.ShardedIndex(200, mi.INNER_PRODUCT, [0] * 33)
+    sh = mi.ShardedIndex(16, mi.L2, [0, 0])
+    with pytest.raises(mi.RoarError):  # shards not loaded yet
+        sh.SearchRoarGraphBatch(np.zeros((2, 16), np.float32), 1, 4)
+    sh.close()
+
+
 def test_mid_scale_built_graph_many_queries(built_lib):
     """200 k points, graph made by the in-HBM builder, 10 000 queries in one launch (more queries
     than resident waves: exercises the dequeue loop), both visited modes, against the oracle."""

@@ -554,8 +554,10 @@ def measure_traffic(args, idx, L, nq_launch):
     if not os.path.exists(prof):
         raise RuntimeError("rocprofv3 not found")
     own_cache = not (args.graph_cache and os.path.exists(args.graph_cache))
-    cache = args.graph_cache if not own_cache else tempfile.mktemp(prefix="roar_bench_graph_", suffix=".index", dir="/tmp")
+    cache = args.graph_cache
     if own_cache:
+        fd, cache = tempfile.mkstemp(prefix="roar_bench_graph_", suffix=".index", dir="/tmp")
+        os.close(fd)
         idx.SaveProjectionGraph(cache)
     steps = 8
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
@@ -568,11 +570,20 @@ def measure_traffic(args, idx, L, nq_launch):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = tempfile.mkdtemp(prefix="roar_pmc_", dir="/tmp")
             try:
-                r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
-                                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+                # own session: a timeout must end the profiler AND the profiled child, not just the former
+                pr = subprocess.Popen([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
+                                      cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+                try:
+                    _, err = pr.communicate(timeout=900)
+                except subprocess.TimeoutExpired:
+                    import signal
+
+                    os.killpg(pr.pid, signal.SIGKILL)  # (the exact process group started above)
+                    pr.communicate()
+                    raise RuntimeError(f"rocprofv3 --pmc {counter} timed out")
                 files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-                if r.returncode != 0 or not files:
-                    raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}")
+                if pr.returncode != 0 or not files:
+                    raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}")
                 vals[counter] = counter_per_launch(max(files, key=os.path.getmtime), counter, steps)  # KB per launch
             finally:
                 shutil.rmtree(out, ignore_errors=True)

@@ -193,6 +193,11 @@ int roar_search_batch_multi(roar_index *const *replicas, uint32_t g, const float
  * block must stay valid and unchanged until the call returns, as for any argument.  NULL on failure. */
 void *roar_host_alloc(uint64_t bytes);
 void roar_host_free(void *p);
+/* The same for a block the caller allocated itself (malloc / memalign / new[], e.g. what the reference's load_data /
+ * data_align return, util.h:64,196): page-lock and map it (hipHostRegister) so that roar_search_batch reads it in place;
+ * unregister before releasing the block. */
+int roar_host_register(void *p, uint64_t bytes);
+int roar_host_unregister(void *p);
 
 /* ---- bipartite two-hop variant (the paper's ablation baseline) -------------------
  * Graph over base nodes [0, n) and training-query nodes [n, n_total); rows of base nodes hold

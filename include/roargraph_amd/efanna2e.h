@@ -67,9 +67,9 @@ class Parameters {
 
 // ---- include/efanna2e/util.h ---------------------------------------------------------------------
 // Same names, arguments, messages and padding rule as the reference's free functions; the implementation is this
-// library's: a file is sized once, read with one sized read and re-strided in memory, and float blocks that will be
-// handed to the GPU (query rows) come from pinned, device-mapped host memory (roar_host_alloc) so that
-// IndexBipartite::SearchRoarGraphBatch reads them in place.  host_free releases what these functions return.
+// library's: a file is sized once, read with one sized read and re-strided in memory.  The blocks are ordinary
+// malloc-compatible memory (delete[] / free / host_free all release them, as with the reference's memalign blocks);
+// pin_block / unpin_block are the opt-in for a query block the GPU should read in place.
 static const unsigned kDataAlignFactor = 8;  // DATA_ALIGN_FACTOR with AVX, util.h:38-48
 
 namespace detail {
@@ -96,28 +96,14 @@ inline FbinHeader open_fbin(const char *filename, std::ifstream &in) {
     return h;
 }
 
-// pinned when a GPU runtime is there, plain 64-byte aligned memory otherwise (the loaders also run on a host-only box)
-inline std::unordered_map<void *, bool> &blocks() {
-    static std::unordered_map<void *, bool> m;
-    return m;
-}
+// Blocks the reference-named loaders hand out are malloc-compatible, as the reference's are (memalign, util.h:64,196):
+// its harness releases them with delete[] / free (tests/test_search_roargraph.cpp:242-247) and so may a ported caller.
 inline void *host_alloc(uint64_t bytes) {
-    // query-sized blocks only: pinning a multi-gigabyte base file would cost more than it can ever save
-    void *p = bytes <= (256ull << 20) ? roar_host_alloc(bytes) : nullptr;
-    const bool pinned = p != nullptr;
-    if (!p) p = aligned_alloc(64, (size_t)((bytes + 63) / 64 * 64));
+    void *p = aligned_alloc(64, (size_t)((bytes + 63) / 64 * 64));
     if (!p) throw std::bad_alloc();
-    blocks()[p] = pinned;
     return p;
 }
-inline void host_free(void *p) {
-    if (!p) return;
-    auto it = blocks().find(p);
-    const bool pinned = it != blocks().end() && it->second;
-    if (it != blocks().end()) blocks().erase(it);
-    if (pinned) roar_host_free(p);
-    else free(p);
-}
+inline void host_free(void *p) { free(p); }
 
 // rows of `d` values -> rows of `stride` values, zero filled
 template <typename T>
@@ -131,6 +117,13 @@ inline void restride(const T *src, uint64_t n, uint64_t d, T *dst, uint64_t stri
 }  // namespace detail
 
 inline void host_free(void *block) { detail::host_free(block); }
+
+// Opt-in fast path for a query block that the caller keeps alive and unchanged across searches: page-lock it and map it
+// into the GPU's address space (hipHostRegister), so that IndexBipartite::SearchRoarGraphBatch reads the rows in place --
+// no staging copy, no host-to-device copy in front of the kernel.  unpin_block BEFORE the block is released.  Returns
+// false (and changes nothing) when there is no GPU runtime or the block cannot be locked; searching it still works.
+inline bool pin_block(void *block, uint64_t bytes) { return roar_host_register(block, bytes) == ROAR_OK; }
+inline void unpin_block(void *block) { (void)roar_host_unregister(block); }
 
 // util.h:106-127: header of an fbin / ibin file; (payload / dim / sizeof(T)) must equal the point count
 template <typename T>
@@ -157,7 +150,7 @@ void load_gt_meta(const char *filename, unsigned &points_num, unsigned &dim) {
     if (contained != 2u * h.n) throw std::runtime_error("Data file size wrong!");
 }
 
-// util.h:179-211: the payload as rows strided at the dimension rounded up to 8, zero filled (pinned block)
+// util.h:179-211: the payload as rows strided at the dimension rounded up to 8, zero filled
 template <typename T>
 void load_data(const char *filename, uint32_t &points_num, uint32_t &dim, T *&data) {
     std::ifstream in;

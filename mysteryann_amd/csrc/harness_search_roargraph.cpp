@@ -158,6 +158,9 @@ int main(int argc, char **argv) {
         uint32_t padded = (q_dim + 7) / 8 * 8;
         float *aligned_query_data = efanna2e::data_align(query_data, q_pts, padded);
         q_dim = padded;
+        // the query block stays where it is for the whole run: let the GPU read it in place (opt-in; the block itself is
+        // ordinary memory, released below like the reference releases its own, tests/test_search_roargraph.cpp:246)
+        const bool pinned = efanna2e::pin_block(aligned_query_data, (uint64_t)q_pts * q_dim * sizeof(float));
 
         uint32_t gt_pts, gt_dim;
         uint32_t *gt_ids = nullptr;
@@ -293,7 +296,8 @@ int main(int argc, char **argv) {
                 evaluation_out << std::endl;
             }
         }
-        efanna2e::host_free(aligned_query_data);
+        if (pinned) efanna2e::unpin_block(aligned_query_data);
+        free(aligned_query_data);
         delete[] gt_ids;
         delete[] gt_dists;
     } catch (const std::exception &ex) {

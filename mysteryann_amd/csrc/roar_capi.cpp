@@ -202,6 +202,23 @@ struct roar_index {
 
 namespace {
 
+// Every entry point that selects a device puts the calling thread's current device back when it returns: a caller that
+// also uses torch / HIP on another device must not find its context moved (a replica lives on its own device).
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+    }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceRestore(const DeviceRestore &) = delete;
+    DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
+
 int use_device(roar_index *idx) {
     HIP_TRY(hipSetDevice(idx->device));
     return ROAR_OK;
@@ -800,6 +817,7 @@ void roar_set_last_error(const char *msg) {
 }
 
 int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
+    DeviceRestore keep_device_;
     if (!out) return fail(ROAR_ERR_ARG, "null output pointer");
     *out = nullptr;
     if (dim == 0) return fail(ROAR_ERR_ARG, "dimension must be positive");
@@ -844,6 +862,7 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
 }
 
 void roar_destroy(roar_index *idx) {
+    DeviceRestore keep_device_;
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     free_graph(idx);
@@ -865,6 +884,7 @@ void roar_destroy(roar_index *idx) {
 }
 
 int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_stride_floats) {
+    DeviceRestore keep_device_;
     if (!idx || !rows || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
     if (row_stride_floats < idx->dim) return fail(ROAR_ERR_ARG, "row stride smaller than the dimension");
     int e = use_device(idx);
@@ -886,6 +906,7 @@ int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_s
 }
 
 int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats) {
+    DeviceRestore keep_device_;
     if (!idx || !rows_dev || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
     if (row_stride_floats < idx->dim_pad || (row_stride_floats & 3))
         return fail(ROAR_ERR_ARG, "device rows need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
@@ -902,6 +923,7 @@ int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uin
 }
 
 int roar_load_base_fbin(roar_index *idx, const char *path) {
+    DeviceRestore keep_device_;
     if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ROAR_ERR_IO, "open file error");  // util.h:109-112
@@ -952,6 +974,7 @@ int roar_load_base_fbin(roar_index *idx, const char *path) {
 }
 
 int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t *offsets, const uint32_t *nbrs) {
+    DeviceRestore keep_device_;
     if (!idx || !offsets || (n && !nbrs && offsets[n] != 0)) return fail(ROAR_ERR_ARG, "bad graph arguments");
     if (n == 0 || n >= (1ull << 31)) return fail(ROAR_ERR_ARG, "graph must have between 1 and 2^31 nodes");
     if (ep >= n) return fail(ROAR_ERR_FORMAT, "entry point %u outside the graph (%llu nodes)", ep, (unsigned long long)n);
@@ -1041,6 +1064,7 @@ int roar_load_graph_file(roar_index *idx, const char *path) {
 }
 
 int roar_save_graph_file(roar_index *idx, const char *path) {
+    DeviceRestore keep_device_;
     if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
     if (idx->gn == 0) return fail(ROAR_ERR_ARG, "no graph loaded");
     {
@@ -1063,6 +1087,7 @@ int roar_save_graph_file(roar_index *idx, const char *path) {
 
 int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *nedges, uint64_t *offsets,
                        uint32_t *nbrs) {
+    DeviceRestore keep_device_;
     if (!idx) return fail(ROAR_ERR_ARG, "bad arguments");
     if (idx->gn) {
         int e = use_device(idx);
@@ -1078,6 +1103,7 @@ int roar_get_graph_csr(roar_index *idx, uint32_t *ep, uint64_t *n, uint64_t *ned
 }
 
 int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
+    DeviceRestore keep_device_;
     if (!idx || !bp) return fail(ROAR_ERR_ARG, "bad arguments");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "build needs base vectors in HBM");
     const uint32_t M = bp->M, base_cap = bp->base_cap, max_degree = bp->max_degree, L_build = bp->L_build;
@@ -1297,6 +1323,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
 // BuildRoarGraph in its batch-synchronous device form (kernels and the mapping to the reference's steps: roar_rgbuild.hip)
 int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                                 uint32_t M_pjbp, uint32_t L_pjpq) {
+    DeviceRestore keep_device_;
     if (!idx || !lists_dev || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
     if (M_pjbp == 0 || M_pjbp > 128) return fail(ROAR_ERR_ARG, "M_pjbp must be in 1..128");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
@@ -1457,6 +1484,7 @@ int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint
 
 int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                          uint32_t M_pjbp, uint32_t L_pjpq) {
+    DeviceRestore keep_device_;
     if (!idx || !learn_knn || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
     const uint32_t C = std::min<uint32_t>(std::min<uint32_t>(M_sq ? M_sq : K, K), 255u);
@@ -1478,6 +1506,7 @@ int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_
 }
 
 int roar_init_visited_pool(roar_index *idx, uint32_t slots) {
+    DeviceRestore keep_device_;
     if (!idx || idx->n == 0) return fail(ROAR_ERR_ARG, "InitVisitedListPool before the base vectors were loaded");
     int e = use_device(idx);
     if (e) return e;
@@ -1488,13 +1517,14 @@ int roar_init_visited_pool(roar_index *idx, uint32_t slots) {
 namespace {
 int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
                   uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev, uint32_t *scanned_dev,
-                  uint32_t *short_count_dev, void *hip_stream, const uint32_t *ready_dev);
+                  uint32_t *short_count_dev, void *hip_stream, const uint32_t *ready_dev, const LaunchPlan *planned = nullptr);
 }
 
 int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats,
                              uint32_t k, uint32_t L_pq, uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev,
                              uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
                              void *hip_stream) {
+    DeviceRestore keep_device_;
     return search_device(idx, queries_dev, nq, qstride_floats, k, L_pq, ids_dev, dists_dev, cmps_dev, hops_dev, scanned_dev,
                          short_count_dev, hip_stream, nullptr);
 }
@@ -1503,7 +1533,7 @@ namespace {
 // ready_dev: see RoarSearchParams::ready (the host-buffer path with a pageable query block)
 int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
                   uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev, uint32_t *scanned_dev,
-                  uint32_t *short_count_dev, void *hip_stream, const uint32_t *ready_dev) {
+                  uint32_t *short_count_dev, void *hip_stream, const uint32_t *ready_dev, const LaunchPlan *planned) {
     if (!idx || !ids_dev || !dists_dev || (nq && !queries_dev)) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (qstride_floats < idx->dim_pad || (qstride_floats & 3))
@@ -1511,7 +1541,8 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
     int e = use_device(idx);
     if (e) return e;
     LaunchPlan plan;
-    if ((e = plan_search(idx, nq, k, L_pq, &plan))) return e;
+    if (planned) plan = *planned;
+    else if ((e = plan_search(idx, nq, k, L_pq, &plan))) return e;
     RoarSearchParams &p = plan.p;
     p.queries = queries_dev;
     p.qstride = qstride_floats;
@@ -1633,6 +1664,7 @@ int search_one(roar_index *idx, roar_index::OneQuery &req) {
 int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                       uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
                       uint32_t *scanned) {
+    DeviceRestore keep_device_;
     if (!idx || !ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
@@ -1655,11 +1687,14 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
     uint32_t qs = 0;
     bool deferred = false;
     if ((e = stage_queries(idx, queries, nq, qstride_floats, k, &qdev, &qs, &deferred))) return e;
+    LaunchPlan probe;
+    bool have_plan = false;
     if (deferred) {
         // the kernel forms that can wait for the packing thread: one wave per query, no hub bitmap, not instrumented
-        LaunchPlan probe;
-        const bool gate = plan_search(idx, nq, k, L_pq, &probe) == ROAR_OK && probe.sel.form == ROAR_FORM_SEARCH &&
-                          probe.sel.waves == 1 && !probe.sel.hub && !probe.sel.prof;
+        // (the plan made here is the one the launch uses: planning can be expensive -- tag pools, hub rows)
+        if ((e = plan_search(idx, nq, k, L_pq, &probe))) return e;
+        have_plan = true;
+        const bool gate = probe.sel.form == ROAR_FORM_SEARCH && probe.sel.waves == 1 && !probe.sel.hub && !probe.sel.prof;
         if (!gate) {  // pack in front of the launch
             pack_queries(idx, queries, nq, qstride_floats);
             deferred = false;
@@ -1671,15 +1706,21 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
     uint32_t *d_hops = d_cmps + nq;
     uint32_t *d_scan = d_hops + nq;
     uint32_t *d_short = d_scan + nq;
-    e = search_device(idx, qdev, nq, qs, k, L_pq, d_ids, d_dists, d_cmps, d_hops, d_scan, d_short, idx->stream,
-                      deferred ? idx->ready_dev : nullptr);
+    // The gated launch waits for rows that are packed behind it -- by a helper thread that is started BEFORE the launch,
+    // so that a launch call that only returns when the kernel has finished (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL,
+    // a debugger or a tool that serialises dispatches) still finds its rows arriving.  No helper thread, no gate.
+    std::thread packer;
     if (deferred) {
-        if (e) {  // nothing was launched: no one is waiting for the rows
-            *idx->ready_pin = (uint32_t)nq;
-            return e;
+        try {
+            packer = std::thread(pack_queries, idx, queries, nq, qstride_floats);
+        } catch (...) {
+            pack_queries(idx, queries, nq, qstride_floats);
+            deferred = false;
         }
-        pack_queries(idx, queries, nq, qstride_floats);
     }
+    e = search_device(idx, qdev, nq, qs, k, L_pq, d_ids, d_dists, d_cmps, d_hops, d_scan, d_short, idx->stream,
+                      deferred ? idx->ready_dev : nullptr, have_plan ? &probe : nullptr);
+    if (packer.joinable()) packer.join();  // (plain memcpy: it always runs to the end, launch or no launch)
     if (e) return e;
     return fetch_results(idx, nq, k, ids, dists, cmps, hops, scanned);
 }
@@ -1688,6 +1729,7 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
 // ---- replicated index, one query block split over g devices (BASELINE configs[3]) --------------------
 
 int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
+    DeviceRestore keep_device_;
     if (!src || !out) return fail(ROAR_ERR_ARG, "bad arguments");
     *out = nullptr;
     if (!src->base || src->n == 0) return fail(ROAR_ERR_ARG, "clone before base vectors were loaded");
@@ -1708,6 +1750,8 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
     dst->search_kernel = src->search_kernel;
     dst->pool_form = src->pool_form;
     dst->combine = src->combine;
+    dst->hub_mode = src->hub_mode;
+    dst->profile = src->profile;
     if ((e = alloc_base(dst, src->n))) return bail(e);
     // rows are re-strided to the padded dimension if the source adopted a wider block
     hipError_t he = hipSuccess;
@@ -1730,7 +1774,8 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
         dst->gn = src->gn;
         dst->nedges = src->nedges;  // the host CSR copy is rebuilt from the device rows if it is ever asked for
     }
-    HIP_TRY(hipDeviceSynchronize());
+    he = hipDeviceSynchronize();
+    if (he != hipSuccess) return bail(fail(ROAR_ERR_DEVICE, "replica on device %d: %s", device, hipGetErrorString(he)));
     *out = dst;
     return ROAR_OK;
 }
@@ -1738,6 +1783,7 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
 int roar_search_batch_multi(roar_index *const *replicas, uint32_t g, const float *queries, uint64_t nq, uint32_t qstride_floats,
                             uint32_t k, uint32_t L_pq, uint32_t *ids, float *dists, uint32_t *cmps, uint32_t *hops,
                             uint32_t *scanned) {
+    DeviceRestore keep_device_;
     if (!replicas || g == 0 || g > 64) return fail(ROAR_ERR_ARG, "between 1 and 64 replicas");
     if (!ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
     for (uint32_t r = 0; r < g; ++r) {
@@ -1807,6 +1853,26 @@ void roar_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+int roar_host_register(void *p, uint64_t bytes) {
+    if (!p || bytes == 0) return fail(ROAR_ERR_ARG, "bad arguments");
+    const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ROAR_ERR_DEVICE, "hipHostRegister of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    return ROAR_OK;
+}
+
+int roar_host_unregister(void *p) {
+    if (!p) return fail(ROAR_ERR_ARG, "bad arguments");
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ROAR_ERR_DEVICE, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    }
+    return ROAR_OK;
+}
+
 
 // ---- bipartite two-hop variant -------------------------------------------------
 
@@ -1840,6 +1906,7 @@ inline uint64_t splitmix64(uint64_t x) {
 }  // namespace
 
 int roar_set_bipartite_csr(roar_index *idx, uint64_t n_total, const uint64_t *offsets, const uint32_t *nbrs) {
+    DeviceRestore keep_device_;
     if (!idx || !offsets || (n_total && !nbrs && offsets[n_total] != 0)) return fail(ROAR_ERR_ARG, "bad graph arguments");
     if (n_total == 0 || n_total >= (1ull << 32)) return fail(ROAR_ERR_ARG, "graph must have between 1 and 2^32 - 1 nodes");
     for (uint64_t i = 0; i < n_total; ++i)
@@ -1981,6 +2048,7 @@ int roar_search_bipartite_batch_device(roar_index *idx, const float *queries_dev
                                        uint32_t k, uint32_t L_pq, const uint32_t *init_ids_dev, uint32_t n_init,
                                        uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev,
                                        uint32_t *scanned_dev, uint32_t *short_count_dev, void *hip_stream) {
+    DeviceRestore keep_device_;
     if (!idx || !queries_dev || !ids_dev || !dists_dev || !init_ids_dev) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (n_init == 0 || n_init > 64) return fail(ROAR_ERR_ARG, "between 1 and 64 entry points per query");
@@ -2016,6 +2084,7 @@ int roar_search_bipartite_batch_device(roar_index *idx, const float *queries_dev
 int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                                 uint32_t L_pq, const uint32_t *init_ids, uint32_t n_init, uint32_t *ids, float *dists,
                                 uint32_t *cmps, uint32_t *hops) {
+    DeviceRestore keep_device_;
     if (!idx || !ids || !dists || (nq && !queries)) return fail(ROAR_ERR_ARG, "bad search arguments");
     if (nq == 0) return ROAR_OK;
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
@@ -2061,6 +2130,7 @@ int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t 
 
 int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, const uint32_t *ids,
                    uint32_t m, float *out) {
+    DeviceRestore keep_device_;
     if (!idx || !queries || !ids || !out) return fail(ROAR_ERR_ARG, "bad arguments");
     if (!idx->base) return fail(ROAR_ERR_ARG, "distances before base vectors were loaded");
     if (nq == 0 || m == 0) return ROAR_OK;
@@ -2072,9 +2142,19 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     if (e) return e;
     float *q_dev = nullptr, *o_dev = nullptr;
     uint32_t *i_dev = nullptr;
-    std::vector<float> buf((size_t)nq * idx->dim_pad, 0.0f);
+    std::vector<float> buf;
+    try {
+        buf.assign((size_t)nq * idx->dim_pad, 0.0f);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory");
+    }
     for (uint64_t i = 0; i < nq; ++i)
         memcpy(buf.data() + i * idx->dim_pad, queries + i * qstride_floats, idx->dim * sizeof(float));
+    struct Free {  // every exit below releases the three device blocks
+        float *&q, *&o;
+        uint32_t *&i;
+        ~Free() { (void)hipFree(q), (void)hipFree(o), (void)hipFree(i); }
+    } free_all{q_dev, o_dev, i_dev};
     HIP_TRY(hipMalloc((void **)&q_dev, buf.size() * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&i_dev, (size_t)nq * m * 4));
     HIP_TRY(hipMalloc((void **)&o_dev, (size_t)nq * m * 4));
@@ -2099,14 +2179,12 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "distance kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, o_dev, (size_t)nq * m * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(q_dev);
-    (void)hipFree(i_dev);
-    (void)hipFree(o_dev);
     return ROAR_OK;
 }
 
 int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                           uint32_t *ids_dev, float *dists_dev, void *hip_stream) {
+    DeviceRestore keep_device_;
     if (!idx || !queries_dev || !ids_dev) return fail(ROAR_ERR_ARG, "bad kNN arguments");
     if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "exact kNN before base vectors were loaded");
     if (k == 0 || k > 128 || k > idx->n) return fail(ROAR_ERR_ARG, "k must be in 1..min(128, n)");
@@ -2122,10 +2200,16 @@ int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq
     auto cleanup = [&]() {
         (void)hipFree(cand); (void)hipFree(cursor); (void)hipFree(tau); (void)hipFree(bnorm); (void)hipFree(ovf);
     };
-    HIP_TRY(hipMalloc(&cursor, chunk * 4));
-    HIP_TRY(hipMalloc(&tau, chunk * 4));
-    HIP_TRY(hipMalloc(&ovf, 4));
-    if (!idx->ip) HIP_TRY(hipMalloc(&bnorm, idx->n * 4));
+    {
+        hipError_t he = hipMalloc(&cursor, chunk * 4);
+        if (he == hipSuccess) he = hipMalloc(&tau, chunk * 4);
+        if (he == hipSuccess) he = hipMalloc(&ovf, 4);
+        if (he == hipSuccess && !idx->ip) he = hipMalloc(&bnorm, idx->n * 4);
+        if (he != hipSuccess) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "out of device memory for the exact kNN workspaces: %s", hipGetErrorString(he));
+        }
+    }
     for (;;) {
         if (hipMalloc(&cand, chunk * cap * 8) != hipSuccess) {
             cleanup();
@@ -2159,6 +2243,7 @@ int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq
 
 int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids,
                    float *dists) {
+    DeviceRestore keep_device_;
     if (!idx || !queries || !ids) return fail(ROAR_ERR_ARG, "bad kNN arguments");
     if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
     if (nq == 0) return ROAR_OK;
@@ -2167,11 +2252,22 @@ int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     const uint64_t chunk = std::min<uint64_t>(nq, 1u << 18);
     float *q_dev = nullptr, *d_dev = nullptr;
     uint32_t *i_dev = nullptr;
-    std::vector<float> buf((size_t)chunk * idx->dim_pad);
-    HIP_TRY(hipMalloc((void **)&q_dev, buf.size() * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&i_dev, (size_t)chunk * k * 4));
-    HIP_TRY(hipMalloc((void **)&d_dev, (size_t)chunk * k * 4));
+    std::vector<float> buf;
+    try {
+        buf.resize((size_t)chunk * idx->dim_pad);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory");
+    }
     auto cleanup = [&]() { (void)hipFree(q_dev); (void)hipFree(i_dev); (void)hipFree(d_dev); };
+    {
+        hipError_t he = hipMalloc((void **)&q_dev, buf.size() * sizeof(float));
+        if (he == hipSuccess) he = hipMalloc((void **)&i_dev, (size_t)chunk * k * 4);
+        if (he == hipSuccess) he = hipMalloc((void **)&d_dev, (size_t)chunk * k * 4);
+        if (he != hipSuccess) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "out of device memory for the exact kNN staging blocks: %s", hipGetErrorString(he));
+        }
+    }
     for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
         const uint64_t cnt = std::min<uint64_t>(chunk, nq - q0);
         std::fill(buf.begin(), buf.begin() + cnt * idx->dim_pad, 0.0f);
@@ -2192,6 +2288,7 @@ int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
 
 int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids_dev,
                            const float *dists_dev, uint32_t *out_ids_dev, float *out_dists_dev, void *hip_stream) {
+    DeviceRestore keep_device_;
     if (nshards == 0 || nshards > 32 || k == 0) return fail(ROAR_ERR_ARG, "merge needs 1..32 shards and k > 0");
     if (!ids_dev || !dists_dev || !out_ids_dev || !out_dists_dev) return fail(ROAR_ERR_ARG, "bad merge arguments");
     int count = 0;
@@ -2204,6 +2301,7 @@ int roar_merge_topk_device(int device, uint32_t nshards, uint64_t nq, uint32_t k
 }
 
 int roar_rebase_ids_device(int device, uint32_t *ids_dev, uint64_t count, uint32_t base, void *hip_stream) {
+    DeviceRestore keep_device_;
     if (!ids_dev && count) return fail(ROAR_ERR_ARG, "bad rebase arguments");
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0)
@@ -2216,6 +2314,7 @@ int roar_rebase_ids_device(int device, uint32_t *ids_dev, uint64_t count, uint32
 
 int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids, const float *dists,
                      int pool_in_registers, uint32_t *snap) {
+    DeviceRestore keep_device_;
     if (!ops || !ids || !dists || !snap || capacity == 0 || capacity > 64)
         return fail(ROAR_ERR_ARG, "queue trace: capacity 1..64 and non-null arrays");
     int count = 0;
@@ -2244,6 +2343,7 @@ int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_
 }
 
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq) {
+    DeviceRestore keep_device_;
     if (!idx || !out) return fail(ROAR_ERR_ARG, "bad arguments");
     if (!idx->prof_dev || idx->prof_nq == 0) return fail(ROAR_ERR_ARG, "no instrumented search has run (option profile_phases)");
     if (nq > idx->prof_nq) return fail(ROAR_ERR_ARG, "the last instrumented launch had %llu queries", (unsigned long long)idx->prof_nq);
@@ -2296,6 +2396,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
 }
 
 int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
+    DeviceRestore keep_device_;
     if (!idx || !key || !value) return fail(ROAR_ERR_ARG, "bad arguments");
     std::string k(key);
     if (k == "n") *value = (int64_t)idx->n;

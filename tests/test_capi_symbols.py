@@ -43,6 +43,30 @@ def test_facade_header_compiles_without_device(tmp_path):
     assert os.system(str(exe)) == 0
 
 
+def test_facade_loader_blocks_are_released_like_the_references(tmp_path, golden_dir):
+    """A ported harness releases what load_data / data_align return with delete[] / free
+    (tests/test_search_roargraph.cpp:242-247; the reference allocates them with memalign, util.h:64,196): the facade's
+    blocks must be malloc-compatible (round 2 handed out hipHostMalloc blocks: glibc aborted on delete[]).  pin_block is
+    the opt-in and degrades to `false` without a GPU."""
+    src = tmp_path / "t.cpp"
+    fb = os.path.join(golden_dir, "ip_200.query.fbin")
+    src.write_text(
+        '#include "roargraph_amd/efanna2e.h"\n'
+        "int main(){ unsigned n = 0, d = 0; efanna2e::load_meta<float>(\"%s\", n, d);\n"
+        "  float *q = nullptr; efanna2e::load_data<float>(\"%s\", n, d, q);\n"
+        "  unsigned dd = (d + 7) / 8 * 8; float *a = efanna2e::data_align(q, n, dd);\n"
+        "  bool pinned = efanna2e::pin_block(a, (uint64_t)n * dd * 4);\n"
+        "  float s = 0; for (unsigned i = 0; i < n * dd; ++i) s += a[i];\n"
+        "  if (pinned) efanna2e::unpin_block(a);\n"
+        "  delete[] a;\n"
+        "  float *b = nullptr; efanna2e::load_data<float>(\"%s\", n, d, b); free(b);\n"
+        "  return (n == 64 && dd == 200 && s == s) ? 0 : 1; }\n" % (fb, fb, fb))
+    exe = tmp_path / "t"
+    csrc = os.path.join(ROOT, "mysteryann_amd", "csrc")
+    assert os.system(f"g++ -std=c++17 -I{ROOT}/include {src} -o {exe} -L{csrc} -lroargraph_amd -Wl,-rpath,{csrc}") == 0
+    assert os.system(f"{exe} > /dev/null") == 0
+
+
 def _gpu_present():
     import torch
 

@@ -859,6 +859,62 @@ def test_pinned_query_block_is_read_in_place(golden_dir, built_lib):
     idx.close()
 
 
+def test_registered_query_block_is_read_in_place(golden_dir, built_lib):
+    """roar_host_register (what the facade's opt-in pin_block calls) on an ordinary malloc'ed block: same results, and the
+    block is released by plain free() after roar_host_unregister -- the reference's harness releases its query block with
+    delete[] (tests/test_search_roargraph.cpp:246), so the loaders must hand out malloc-compatible memory."""
+    import ctypes as C
+
+    from mysteryann_amd import capi
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.expected.npz"))
+    idx, q = _index("ip_200", golden_dir, 2)
+    lib = capi.lib()
+    libc = C.CDLL(None)
+    libc.aligned_alloc.restype = C.c_void_p
+    libc.aligned_alloc.argtypes = [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    nq, d = q.shape
+    nbytes = (nq * d * 4 + 4095) // 4096 * 4096
+    ptr = libc.aligned_alloc(4096, nbytes)
+    blk = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(nq, d))
+    blk[:] = q
+    capi.check(lib.roar_host_register(ptr, nbytes))
+    ids = np.zeros((nq, K), np.uint32)
+    dists = np.zeros((nq, K), np.float32)
+    capi.check(lib.roar_search_batch(idx._h, C.cast(ptr, C.POINTER(C.c_float)), nq, d, K, 50, capi.u32p(ids), capi.f32p(dists),
+                                     None, None, None))
+    assert np.array_equal(ids, exp["ids_50"]) and np.array_equal(dists, exp["dists_50"])
+    capi.check(lib.roar_host_unregister(ptr))
+    libc.free(ptr)
+    idx.close()
+
+
+def test_pageable_host_path_survives_a_blocking_launch(golden_dir):
+    """The pageable host-buffer call launches a kernel that waits for rows the host packs behind the launch.  With
+    HIP_LAUNCH_BLOCKING=1 the launch call only returns when the kernel has finished, so the packing must not depend on
+    it returning (round 2 packed on the calling thread after the launch: a hang).  Run in a child process with a timeout."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mysteryann_amd import index as mi, fileio\n"
+        "g = %r\n"
+        "exp = np.load(os.path.join(g, 'ip_200.expected.npz'))\n"
+        "q = fileio.read_fbin(os.path.join(g, 'ip_200.query.fbin'))\n"
+        "idx = mi.IndexBipartite(200, 0, mi.INNER_PRODUCT, None)\n"
+        "idx.LoadSearchNeededData(os.path.join(g, 'ip_200.base.fbin'))\n"
+        "idx.LoadProjectionGraph(os.path.join(g, 'ip_200.roar.index'))\n"
+        "r = idx.SearchRoarGraphBatch(q, 10, 50)\n"
+        "assert np.array_equal(r['ids'], exp['ids_50']) and np.array_equal(r['dists'], exp['dists_50'])\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), golden_dir)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HIP_LAUNCH_BLOCKING="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def _yardsticks():
     import glob
 

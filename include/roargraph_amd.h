@@ -36,10 +36,15 @@ enum {
 
 /* visited-set policy, option "visited_mode" (replaces VisitedList / VisitedListPool,
  * include/visited_list_pool.h:8-74):
- *   EXACT  per-slot u8 epoch tags in HBM: mass[id]==curV semantics, cmps identical to the reference.
- *   LDS    per-query set-associative tag table in LDS that may forget (never a false positive);
- *          ids / distances / hops stay identical to the reference, cmps can only be >= it. */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the on-chip table up to L_pq ~ 500-1950 (the switch point depends on the graph's density and on the hub form, csrc/roar_capi.cpp plan_search), HBM tags beyond */ };
+ *   EXACT          per-workgroup u8 epoch tags in HBM: mass[id]==curV semantics.
+ *   LDS            per-query set-associative tag table in LDS, exact: the table never gives an entry up, an id that
+ *                  finds its set full is looked up / marked in the workgroup's spill list in HBM (u16 epoch tags).
+ *   LDS_FORGETFUL  the same table, a full set overwrites a victim entry (never a false positive): a forgotten node
+ *                  is scored again if met again; nothing is ever stored to HBM.
+ * ids / distances / hops are identical to the reference in every mode; cmps is the reference's in EXACT and LDS and can
+ * only be >= it in LDS_FORGETFUL.  (If HBM cannot hold one spill list per resident workgroup -- 2 n bytes each -- an LDS
+ * launch runs forgetful; info key "last_visited_forgetful" says so.) */
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: chosen per launch from L_pq and the graph, csrc/roar_capi.cpp plan_search */, ROAR_VISITED_LDS_FORGETFUL = 3 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -304,7 +309,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
 /* ---- options / introspection ----------------------------------------------------------------
  * Parameters::Set / Get  include/efanna2e/parameters.h:15-57 carry L_pq per call in the reference;
  * here L_pq is an argument and the remaining knobs are integers:
- *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_AUTO (default AUTO)
+ *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_LDS_FORGETFUL | ROAR_VISITED_AUTO (default AUTO)
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow, at most six
  *                    with the on-chip tag table and rows of 768 bytes or more)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)

@@ -161,6 +161,12 @@ struct roar_index {
     uint32_t *epochs = nullptr;
     uint32_t slots = 0;
     uint64_t tag_stride = 0;
+    // LDS mode, exact form: spill lists, one u16[n] list per resident workgroup + its epoch (roar_search_v2.h visited_ldsn)
+    uint16_t *spill = nullptr;
+    uint32_t *spill_epochs = nullptr;
+    uint32_t spill_slots = 0;
+    uint64_t spill_stride = 0;  // elements
+    int last_forgetful = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;  // stream of the most recent search launch, and whether it used the HBM tag lists
@@ -266,6 +272,11 @@ void free_tags(roar_index *idx) {
     idx->tags = nullptr;
     idx->epochs = nullptr;
     idx->slots = 0;
+    if (idx->spill) (void)hipFree(idx->spill);
+    if (idx->spill_epochs) (void)hipFree(idx->spill_epochs);
+    idx->spill = nullptr;
+    idx->spill_epochs = nullptr;
+    idx->spill_slots = 0;
 }
 
 // util.h:214-225
@@ -317,6 +328,40 @@ int ensure_tags(roar_index *idx, uint32_t *slots_io) {
     HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->epochs, 0, (size_t)slots * sizeof(uint32_t)));
     idx->slots = slots;
+    return ROAR_OK;
+}
+
+// Spill lists of the exact LDS form: `slots` lists or none -- a launch with fewer workgroups than the chip holds would cost
+// more than the exact cmps count is worth, so when HBM cannot hold them the launch runs the forgetful form instead
+// (*granted = false; results are the same, cmps may exceed the reference's).
+int ensure_spill(roar_index *idx, uint32_t slots, bool *granted) {
+    *granted = true;
+    if (idx->spill && idx->spill_slots >= slots) return ROAR_OK;
+    const uint64_t stride = std::max<uint64_t>(8, ((idx->n + 7) / 8) * 8);
+    if (affordable_slots(stride * 2, idx->spill ? (uint64_t)idx->spill_slots * idx->spill_stride * 2 : 0, slots) < slots) {
+        *granted = false;
+        return ROAR_OK;
+    }
+    if (idx->spill) (void)hipFree(idx->spill);
+    if (idx->spill_epochs) (void)hipFree(idx->spill_epochs);
+    idx->spill = nullptr;
+    idx->spill_epochs = nullptr;
+    idx->spill_slots = 0;
+    idx->spill_stride = stride;
+    hipError_t e = hipMalloc((void **)&idx->spill, (size_t)slots * stride * 2);
+    if (e == hipSuccess) e = hipMemset(idx->spill, 0, (size_t)slots * stride * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&idx->spill_epochs, (size_t)slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(idx->spill_epochs, 0, (size_t)slots * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (idx->spill) (void)hipFree(idx->spill);
+        if (idx->spill_epochs) (void)hipFree(idx->spill_epochs);
+        idx->spill = nullptr;
+        idx->spill_epochs = nullptr;
+        *granted = false;
+        return ROAR_OK;
+    }
+    idx->spill_slots = slots;
     return ROAR_OK;
 }
 
@@ -505,9 +550,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // reference and still beats the HBM tags, 82.1 / 87.6 / 93.1 / 98.5 ms against 85.1 / 91.5 / 96.1 / 101.0 ms at L_pq = 1 500 /
     // 1 600 / 1 700 / 1 800; at 2 000 the HBM tags win, 111.9 against 116.9 ms; scripts/long_pool_probe.py)
     const uint32_t lds_until = use_hub ? 1200u : dense ? 512u : 1950u;
-    const int mode = idx->visited_mode == ROAR_VISITED_AUTO
-                         ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
-                         : idx->visited_mode;
+    int mode = idx->visited_mode == ROAR_VISITED_AUTO
+                   ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
+                   : idx->visited_mode;
+    // LDS: the exact form (ids that find their set full go to the spill list in HBM); LDS_FORGETFUL: a full set overwrites
+    // a victim (cmps >= the reference's, nothing stored to HBM); the builder's searches and the two-hop walk forget
+    bool forget = mode == ROAR_VISITED_LDS_FORGETFUL || idx->building || bipartite;
+    if (mode == ROAR_VISITED_LDS_FORGETFUL) mode = ROAR_VISITED_LDS;
     // bipartite, AUTO: eight waves per query while the pool is short (work per query is far too uneven for one
     // wave each: T2I-10M, 10 000 queries, 14.0 / 20.0 / 32.8 / 44.9 / 68.2 ms at L_pq = 10 / 20 / 50 / 100 / 200 against
     // 20.7 / 26.4 / 39.4 / 46.0 / 68.0 ms with one wave; from L_pq = 500 the waves queue for the shared pool and the
@@ -553,7 +602,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         if ((uint64_t)entries * 2 > 128 * 1024)
             return fail(ROAR_ERR_ARG, "visited table of %u entries does not fit in LDS", entries);
     }
-    p.vis_sets_log2 = sets_log2 | (sets3 ? 0x80000000u : 0u);
+    p.vis_sets_log2 = sets_log2 | (sets3 ? 0x80000000u : 0u);  // (+ bit 30 once the spill lists are known to fit, below)
     uint32_t off = 0;
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
@@ -685,7 +734,20 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         p.tags = idx->tags;
         p.tag_stride = idx->tag_stride;
         p.epochs = idx->epochs;
+    } else if (!forget) {
+        bool granted = false;
+        int e = ensure_spill(idx, plan->grid, &granted);
+        if (e) return e;
+        if (granted) {
+            p.tags = reinterpret_cast<uint8_t *>(idx->spill);
+            p.tag_stride = idx->spill_stride;
+            p.epochs = idx->spill_epochs;
+        } else {
+            forget = true;
+        }
     }
+    if (mode == ROAR_VISITED_LDS && forget) p.vis_sets_log2 |= 0x40000000u;
+    idx->last_forgetful = (mode == ROAR_VISITED_LDS && forget) ? 1 : 0;
     p.counter = idx->counters;
     if (sel.prof) {
         if (idx->prof_cap < nq) {
@@ -1563,10 +1625,10 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
     // Launches of one index on different streams may overlap (each has its own launch cell) -- except where they would
     // share per-workgroup state in HBM: the EXACT-mode tag lists / the spill lists are indexed by workgroup, so such a
     // launch waits for the previous one.
-    if (idx->ev_valid && idx->last_stream != st && (plan.sel.visited_mode == ROAR_VISITED_EXACT || idx->last_used_tags))
+    if (idx->ev_valid && idx->last_stream != st && (p.tags != nullptr || idx->last_used_tags))
         HIP_TRY(hipStreamWaitEvent(st, idx->ev1, 0));
     idx->last_stream = st;
-    idx->last_used_tags = plan.sel.visited_mode == ROAR_VISITED_EXACT;
+    idx->last_used_tags = plan.sel.visited_mode == ROAR_VISITED_EXACT || p.tags != nullptr;
     HIP_TRY(hipEventRecord(idx->ev0, st));
     int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2358,7 +2420,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     if (!idx || !key) return fail(ROAR_ERR_ARG, "bad arguments");
     std::string k(key);
     if (k == "visited_mode") {
-        if (value != ROAR_VISITED_EXACT && value != ROAR_VISITED_LDS && value != ROAR_VISITED_AUTO)
+        if (value != ROAR_VISITED_EXACT && value != ROAR_VISITED_LDS && value != ROAR_VISITED_AUTO && value != ROAR_VISITED_LDS_FORGETFUL)
             return fail(ROAR_ERR_ARG, "bad visited_mode");
         idx->visited_mode = (int)value;
     } else if (k == "waves_per_cu") {
@@ -2411,6 +2473,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "need_normalize") *value = idx->need_normalize ? 1 : 0;
     else if (k == "visited_mode") *value = idx->visited_mode;
     else if (k == "last_visited_mode") *value = idx->last_mode;
+    else if (k == "last_visited_forgetful") *value = idx->last_forgetful;
     else if (k == "last_waves_per_query")
         *value = idx->last_sel.form == ROAR_FORM_BIPARTITE_WG ? 8
                  : idx->last_sel.form == ROAR_FORM_SEARCH ? idx->last_sel.waves : 1;

@@ -31,11 +31,13 @@ struct RoarSearchParams {
     // *short_count).  Two-hop kernels: word 0 only, zeroed by the host before every launch.
     uint32_t *counter;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
-    uint32_t vis_sets_log2;  // bit 31 (search kernel only): the table has 3 << (value & 31) sets
+    uint32_t vis_sets_log2;  // search kernel only: bit 31: the table has 3 << (value & 31) sets; bit 30: forgetful form (a
+                             // full set overwrites a victim; else ids that find their set full go to the spill list below)
     // host-buffer form with a pageable query block: rows [0, *ready) of `queries` (pinned staging) have been written by the
     // host thread that is still packing the rest; null = every row is there (search kernel only)
     const uint32_t *ready;
-    // visited, EXACT mode: one u8[tag_stride] list per resident wave + its epoch
+    // visited, EXACT mode: one u8[tag_stride] list per resident workgroup + its epoch.  LDS mode, exact form: the spill
+    // lists, one u16[tag_stride] list per resident workgroup (tag_stride in elements) + its epoch
     uint8_t *tags;
     uint64_t tag_stride;
     uint32_t *epochs;

@@ -35,14 +35,25 @@ namespace {
 // empty way is claimed with a 32-bit compare-and-swap on the half of the set that holds it: no write / barrier /
 // re-read round per insertion; a lane that loses a race sees the winner's word in the CAS result and tries the next
 // way.  The three probes of a lane are independent, so a round is written branch-free with the three atomics in
-// flight together.  A full set overwrites a victim way; that is the only place the table forgets (the node is then
-// scored again and its key is dropped by the merge as a duplicate or as worse than the pool's last entry).
+// flight together.
+// A FULL set (VisitedList semantics, visited_list_pool.h:8-29, must hold for any number of nodes):
+//   * exact form (default): the table never gives an entry up.  An id that finds its set full and itself absent is
+//     looked up -- and, when new, marked -- in the workgroup's spill list in HBM: u16 epoch tags, one per base point,
+//     the reference's own `mass[id] == curV` test.  An id can only be in the spill list if its set was full when it came,
+//     and sets only fill up, so a miss in a set with a free way needs no look-up: "visited" is exactly "in the table or
+//     tagged", and cmps equals the reference's at every L_pq.  The list's pointer is read from the kernel-argument
+//     segment and the epoch from LDS where they are needed, not held in scalar registers through the hop.
+//   * forgetful form (option visited_mode = LDS_FORGETFUL; the builder's searches): a victim way is overwritten.  The
+//     forgotten node is scored again if it is met again, its key is dropped by the merge as a duplicate or as worse than
+//     the pool's last entry: ids / distances / hops are unchanged, cmps can only exceed the reference's, and nothing is
+//     ever stored to HBM (a one-word mark costs as much as 2-3.5 lines of a row gather, scripts/probe_cost.hip).
 template <int NC>
 __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
-                                             uint32_t sets_log2, bool three, bool (&fresh)[NC]) {
+                                             uint32_t sets_log2, bool three, bool forget, bool (&fresh)[NC]) {
     uint32_t *w[NC];
     uint32_t tag[NC], x[NC], y[NC];
     bool pend[NC];
+    uint32_t spillm = 0;  // bit c: chunk c goes to the spill list (a per-lane word, not one more lane mask in scalar registers)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         uint32_t set = nb[c] & sets_mask;
@@ -77,10 +88,11 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
             low[c] = (t0 == 0) | (t1 == 0);
             oldw[c] = low[c] ? x[c] : y[c];
             cas[c] = pend[c] & !hit & !full;
-            const bool victim = pend[c] & !hit & full;
-            if (victim) reinterpret_cast<uint16_t *>(w[c])[tag[c] & 3u] = (uint16_t)tag[c];
-            fresh[c] |= victim;
-            pend[c] = cas[c];  // visited before, or victim written: done
+            const bool over = pend[c] & !hit & full;  // the set is full and does not hold this id
+            if (over & forget) reinterpret_cast<uint16_t *>(w[c])[tag[c] & 3u] = (uint16_t)tag[c];
+            fresh[c] |= over & forget;
+            spillm |= (over & !forget) ? (1u << c) : 0u;
+            pend[c] = cas[c];  // visited before, victim written, or handed to the spill list: done here
             got[c] = oldw[c];
         }
 #pragma unroll
@@ -100,6 +112,27 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
         any = false;
 #pragma unroll
         for (int c = 0; c < NC; ++c) any |= pend[c];
+    }
+    if (__ballot(spillm != 0)) {  // (never in the forgetful form)
+#if defined(__HIP_DEVICE_COMPILE__)
+        extern __shared__ __align__(16) unsigned char smem_[];
+        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint16_t *const sp = reinterpret_cast<uint16_t *>(*const_cast<uint8_t *const volatile *>(&ka->tags)) +
+                             (u64)blockIdx.x * *const_cast<const uint64_t volatile *>(&ka->tag_stride);
+        const uint32_t ep = reinterpret_cast<const volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_ctrl))[6];
+#else
+        uint16_t *const sp = nullptr;  // (host pass of the compiler: never executed)
+        const uint32_t ep = 0;
+#endif
+        uint32_t tg[NC];  // the look-ups of a lane's chunks are issued together (ids of one row are distinct: no two lanes share a tag)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tg[c] = ((spillm >> c) & 1u) ? (uint32_t)__builtin_nontemporal_load(sp + nb[c]) : ep;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool fr = tg[c] != ep;  // (a lane that did not look up holds ep)
+            if (fr) __builtin_nontemporal_store((uint16_t)ep, sp + nb[c]);
+            fresh[c] |= fr;
+        }
     }
 }
 
@@ -276,8 +309,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     const uint32_t *const ADJ = HUB ? p.adj_hub : p.adj;
     const uint32_t AS = HUB ? p.hub_stride : p.adj_stride;
     const uint32_t L = p.L;
-    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets
+    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets; bit 30: forgetful form
     const bool sets3 = (p.vis_sets_log2 >> 31) != 0;
+    const bool forget = ((p.vis_sets_log2 >> 30) & 1u) != 0;
+    // (exact LDS form: the workgroup's spill list -- u16 epoch tags in HBM -- has its epoch in LDS, ctrl[6])
     const uint32_t sets_mask = (1u << sets_log2) - 1u;
     const uint32_t NONE = 0xFFFFFFFFu;
     uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
@@ -287,6 +322,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         else lds_barrier();
     };
     uint32_t ready_seen = 0;
+    if (MODE == VIS_LDS && !forget) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x == 0) ctrl[6] = (*const_cast<uint32_t *const volatile *>(&ka->epochs))[blockIdx.x];
+#endif
+        block_sync();
+    }
 
     for (;;) {
         uint32_t q = 0;
@@ -323,6 +365,21 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         }
         if (HUB)
             for (uint32_t i = threadIdx.x; i < 512u; i += 64 * W) reinterpret_cast<uint4 *>(hbits)[i] = make_uint4(0, 0, 0, 0);
+        if (MODE == VIS_LDS && !forget) {  // VisitedList::reset (visited_list_pool.h:20-26) of the spill list, u16 epoch
+            uint32_t e16 = ctrl[6] + 1u;
+            if (e16 == 65536u) {  // (every 65 535 queries of this workgroup slot)
+#if defined(__HIP_DEVICE_COMPILE__)
+                const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+                const u64 bytes = *const_cast<const uint64_t volatile *>(&ka->tag_stride) * 2u;
+                uint8_t *sp = *const_cast<uint8_t *const volatile *>(&ka->tags) + (u64)blockIdx.x * bytes;
+                for (u64 i = (u64)threadIdx.x * 16; i < bytes; i += 1024 * W) *reinterpret_cast<uint4 *>(sp + i) = make_uint4(0, 0, 0, 0);
+                __threadfence();
+#endif
+                e16 = 1;
+            }
+            block_sync();
+            if (threadIdx.x == 0) ctrl[6] = e16;
+        }
         if (MODE == VIS_EXACT) {  // VisitedList::reset (visited_list_pool.h:20-26) with a u8 epoch
             epoch++;
             if (epoch == 256u) {
@@ -486,7 +543,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
                             }
                         } else {
-                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, fresh);
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, forget, fresh);
                         }
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
@@ -603,7 +660,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 if (o_cmps) o_cmps[q] = cmps;
                 if (o_hops) o_hops[q] = hops;
                 if (o_scanned) o_scanned[q] = scanned;
-                if (psize < p.k) atomicAdd(p.counter + 2, 1u);  // short queries of this launch (handed over at the end)
+                if (psize < p.k) atomicAdd(*const_cast<uint32_t *const volatile *>(&ka->counter) + 2, 1u);  // short queries of this launch
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
                     o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);
@@ -626,18 +683,31 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         block_sync();
     }
     if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
+    if (MODE == VIS_LDS && !forget && threadIdx.x == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        (*const_cast<uint32_t *const volatile *>(&ka->epochs))[blockIdx.x] = ctrl[6];
+#endif
+    }
     // Launch slot {next query, workgroups done, short queries, -} (one 16-byte cell of the index's ring): the last
     // workgroup to leave hands the short count to the caller and leaves the cell zeroed for the launch that takes it
     // next, so no memset is queued in front of a launch.  (This workgroup's dequeue and short-count atomics were
     // issued before the one below, to the same L2 channel.)
     if (threadIdx.x == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+        const RoarSearchParams *ka = &p;
+#endif
+        uint32_t *const cell = *const_cast<uint32_t *const volatile *>(&ka->counter);
+        uint32_t *const o_short = *const_cast<uint32_t *const volatile *>(&ka->short_count);
         __threadfence();
-        if (atomicAdd(p.counter + 1, 1u) == gridDim.x - 1u) {
-            const uint32_t nshort = atomicExch(p.counter + 2, 0u);
-            if (p.short_count) *p.short_count = nshort;
-            atomicExch(p.counter + 1, 0u);
+        if (atomicAdd(cell + 1, 1u) == gridDim.x - 1u) {
+            const uint32_t nshort = atomicExch(cell + 2, 0u);
+            if (o_short) *o_short = nshort;
+            atomicExch(cell + 1, 0u);
             __threadfence();
-            atomicExch(p.counter, 0u);
+            atomicExch(cell, 0u);
         }
     }
 }

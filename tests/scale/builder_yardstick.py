@@ -16,6 +16,11 @@ ap.add_argument("--n", type=int, default=200_000)
 ap.add_argument("--nq", type=int, default=1000)
 ap.add_argument("--seed", type=int, default=1234)
 ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--Ls", type=int, nargs="+", default=[20, 50, 100])
+ap.add_argument("--name", default="builder_yardstick", help="fixture written: tests/golden/<name>_<n>.json")
+ap.add_argument("--survey-probe", action="store_true",
+                help="add the figures SURVEY.md 3.2 / 6 / 8(d) report for the COMPILED reference builder on this recipe at "
+                     "n = 50 000 (the only numbers the real builder ever produced here) beside the restated builder's")
 args = ap.parse_args()
 n = args.n
 t0 = time.time()
@@ -53,11 +58,17 @@ print(f"restated reference builder: {t_build:.0f}s, ep {ep}, degree avg {deg.mea
 out = {"n": n, "nq": args.nq, "seed": args.seed, "n_learn": n, "M_sq": 100, "M_pjbp": 35, "L_pjpq": 500, "metric": "ip",
        "builder_seconds_cpu_1thread": round(t_build, 1), "ep": int(ep), "avg_degree": float(deg.mean()), "max_degree": int(deg.max()),
        "min_degree": int(deg.min()), "curve": {}}
-for L in (20, 50, 100):
+if args.survey_probe:  # SURVEY.md:137-138 (hops, cmps), :195-199 (degree, recall at 10 / 100 / 500), :302 (recall at 20 / 100)
+    out["survey_probe_of_the_compiled_reference"] = {
+        "n": 50000, "avg_degree": 33.1, "max_degree": 70,
+        "recall_at_10": {"10": 0.792, "20": 0.915, "100": 0.9974, "500": 1.0},
+        "avg_hops": {"10": 14.5, "20": 23.7, "50": 52.8, "100": 102.5, "200": 202.2, "500": 502.0},
+        "avg_cmps": {"10": 675, "20": 1066, "50": 2107, "100": 3519, "200": 5722, "500": 10295}}
+for L in args.Ls:
     r = oracle.search_batch(base, off, nbrs, ep, q, 10, L, 1, threads=args.threads)
     out["curve"][str(L)] = {"recall_at_10": float(oracle.recall(r["ids"], gt, 10)), "avg_cmps": float(r["cmps"].mean()),
                             "avg_hops": float(r["hops"].mean())}
     print(L, out["curve"][str(L)], flush=True)
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden", f"builder_yardstick_{n}.json")
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden", f"{args.name}_{n}.json")
 json.dump(out, open(path, "w"), indent=1)
 print("written", path)

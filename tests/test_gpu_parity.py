@@ -160,7 +160,7 @@ def test_high_degree_rows_and_large_pool(built_lib):
     idx = mi.IndexBipartite(d, n, 1, None)
     idx.SetBaseData(base)
     idx.SetProjectionGraph(5, off, nbrs)
-    for mode in (0, 1):
+    for mode in (0, 1, 3):  # EXACT, LDS (exact: full sets spill to HBM), LDS_FORGETFUL
         idx.set_option("visited_mode", mode)
         # (5000: a pool beyond 4 096 entries takes the pieced second level of the merge's search; the 6 000-node graph
         # never fills it, so this is also the short-of-L_pq pool)
@@ -170,7 +170,7 @@ def test_high_degree_rows_and_large_pool(built_lib):
             assert np.array_equal(r["ids"], o["ids"]), (mode, L)
             assert np.array_equal(r["dists"], o["dists"]), (mode, L)
             assert np.array_equal(r["hops"], o["hops"]), (mode, L)
-            if mode == 0:
+            if mode != 3:
                 assert np.array_equal(r["cmps"], o["cmps"]), (mode, L)
             else:
                 assert (r["cmps"] >= o["cmps"]).all()
@@ -238,16 +238,18 @@ def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
             assert np.array_equal(r["ids"], o["ids"]), (L, ve)
             assert np.array_equal(r["dists"], o["dists"]), (L, ve)
             assert np.array_equal(r["hops"], o["hops"]), (L, ve)
-            assert (r["cmps"] >= o["cmps"]).all()
+            assert np.array_equal(r["cmps"], o["cmps"]), (L, ve)  # a full set spills, it does not forget
     assert idx.info("last_vis_entries") == 4096  # auto at L_pq = 400 on a sparse graph with rows under 768 bytes: the small table (800-byte rows: 12 288)
     with pytest.raises(Exception):
         idx.set_option("vis_entries", 5 * 1024)
     idx.close()
 
 
-def test_forgetful_visited_table_keeps_results(built_lib):
-    """A deliberately tiny LDS tag table forgets constantly: ids / dists / hops must not move,
-    cmps may only grow."""
+def test_full_sets_spill_or_forget_without_moving_results(built_lib):
+    """A deliberately tiny LDS tag table (64 tags) is full all the time.  LDS mode: ids that find their set full go to the
+    workgroup's spill list in HBM -- cmps equals the reference's (VisitedList semantics, visited_list_pool.h:8-29), also
+    through the 2-wave and 4-wave forms and the instrumented path's siblings.  LDS_FORGETFUL mode: a victim is overwritten --
+    ids / dists / hops must not move, cmps may only grow."""
     import oracle
     from mysteryann_amd import index as mi
 
@@ -256,19 +258,54 @@ def test_forgetful_visited_table_keeps_results(built_lib):
     idx = mi.IndexBipartite(d, n, 0, None)
     idx.SetBaseData(base)
     idx.SetProjectionGraph(0, off, nbrs)
-    idx.set_option("visited_mode", 1)
     idx.set_option("vis_entries", 64)
     idx.set_option("hub_mode", 1)  # (with the hub bitmap every node of a 20 000-point graph has an exact visited bit)
     o = oracle.search_batch(base, off, nbrs, 0, q, K, 150, 0)
+    idx.set_option("visited_mode", 3)
     r = idx.SearchRoarGraphBatch(q, K, 150)
+    assert idx.info("last_visited_forgetful") == 1
     assert np.array_equal(r["ids"], o["ids"])
     assert np.array_equal(r["dists"], o["dists"])
     assert np.array_equal(r["hops"], o["hops"])
     assert (r["cmps"] >= o["cmps"]).all() and (r["cmps"] > o["cmps"]).any()
-    idx.set_option("hub_mode", 2)  # ... and then nothing is ever forgotten, however small the table
+    idx.set_option("visited_mode", 1)
+    for kern in (1, 3, 2):  # one, two, four waves per query
+        idx.set_option("search_kernel", kern)
+        for rep in range(2):  # the spill lists' epochs persist across launches
+            r = idx.SearchRoarGraphBatch(q, K, 150)
+            assert idx.info("last_visited_forgetful") == 0
+            for key in ("ids", "dists", "hops", "cmps"):
+                assert np.array_equal(r[key], o[key]), (kern, rep, key)
+    idx.set_option("search_kernel", 0)
+    idx.set_option("hub_mode", 2)  # hub bitmap in front: nothing reaches the table that a hub bit settles
     r = idx.SearchRoarGraphBatch(q, K, 150)
     assert idx.info("last_hub_bitmap") == 1
     assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["cmps"], o["cmps"])
+
+
+def test_spill_list_epoch_wrap(built_lib):
+    """More than 65 535 queries through one resident workgroup: the u16 epoch of its spill list wraps and the list is cleared
+    (VisitedList::reset, visited_list_pool.h:20-26).  Tiny table, tiny pool, one workgroup."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 600, 8, 66000
+    base, q, off, nbrs = _random_case(n, d, 500, 0, seed=19, maxdeg=24)
+    q = np.tile(q, (132, 1))[:nq].copy()
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(3, off, nbrs)
+    idx.set_option("visited_mode", 1)
+    idx.set_option("vis_entries", 64)
+    idx.set_option("hub_mode", 1)
+    idx.set_option("max_grid", 1)
+    o = oracle.search_batch(base, off, nbrs, 3, q[:500], K, 12, 0, threads=4)
+    r = idx.SearchRoarGraphBatch(q, K, 12)
+    for key in ("ids", "hops", "cmps"):
+        assert np.array_equal(r[key][:500], o[key]), key
+    want = np.tile(o["cmps"], 132)[:nq]
+    assert np.array_equal(r["cmps"], want)  # every copy of a query counts the same, before and after the wrap
+    assert np.array_equal(r["ids"], np.tile(o["ids"], (132, 1))[:nq])
 
 
 def test_exact_mode_epoch_wrap(built_lib):

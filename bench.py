@@ -567,11 +567,15 @@ def measure_traffic(args, idx, L, nq_launch):
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # third pass: where the bytes come from -- L2 hits / misses and the L2's memory-side read requests (all / those routed
+        # to the memory controllers).  Optional: a box whose profiler refuses the set just leaves these fields out.
+        L2SET = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", L2SET):
             out = tempfile.mkdtemp(prefix="roar_pmc_", dir="/tmp")
+            names = [counter] if isinstance(counter, str) else list(counter)
             try:
                 # own session: a timeout must end the profiler AND the profiled child, not just the former
-                pr = subprocess.Popen([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
+                pr = subprocess.Popen([prof, "--kernel-trace", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--"] + child,
                                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
                 try:
                     _, err = pr.communicate(timeout=900)
@@ -583,14 +587,33 @@ def measure_traffic(args, idx, L, nq_launch):
                     raise RuntimeError(f"rocprofv3 --pmc {counter} timed out")
                 files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
                 if pr.returncode != 0 or not files:
+                    if counter is L2SET:
+                        log(f"[rank 0] L2 counter pass not available here: rc {pr.returncode} {err.decode(errors='replace')[-200:]}")
+                        continue
                     raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}")
-                vals[counter] = counter_per_launch(max(files, key=os.path.getmtime), counter, steps)  # KB per launch
+                for nm in names:
+                    try:
+                        vals[nm] = counter_per_launch(max(files, key=os.path.getmtime), nm, steps)  # (SIZE counters: KB per launch)
+                    except RuntimeError:
+                        if counter is not L2SET:
+                            raise
             finally:
                 shutil.rmtree(out, ignore_errors=True)
     finally:
         if own_cache and os.path.exists(cache):
             os.remove(cache)
-    return {"traffic": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+    extra = {}
+    if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals and vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"] > 0:
+        extra["l2_hit_share"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])  # of 128-B line requests at the L2
+        extra["beyond_l2_bytes"] = vals["TCC_MISS_sum"] * 128.0  # what the L2 asks the fabric for: Infinity Cache + HBM together
+        extra["l2_requests_per_launch"] = vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]
+    if "TCC_EA0_RDREQ_sum" in vals and vals.get("TCC_EA0_RDREQ_sum", 0) > 0 and "TCC_EA0_RDREQ_DRAM_sum" in vals:
+        extra["l2_read_requests_routed_to_memory_controllers_share"] = vals["TCC_EA0_RDREQ_DRAM_sum"] / vals["TCC_EA0_RDREQ_sum"]
+    if extra:
+        # the Infinity Cache (256 MB, memory side) sits BEHIND these counters: a hit there is still an L2 miss and a
+        # memory-side read request, so HBM-only bytes are not separable with the counters rocprofv3 lists on gfx950
+        extra["frac_hbm_only"] = None
+    return {**extra, "traffic": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
             "traffic_source": f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {steps} launches of a "
                               f"child of this command (same data, graph, L_pq, batches); FETCH_SIZE x 2 (gfx950)",
             "FETCH_SIZE_KB_raw_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw_per_launch": vals["WRITE_SIZE"]}

@@ -344,6 +344,11 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value);
  * {issuing loads, waiting + FMAs, reduction + packing}, number of passes, candidates that reached the merge; 3 spare. */
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
 
+/* Testing hook for the error paths: the n-th device allocation the library makes from now on fails as if HBM were
+ * exhausted (n <= 0 disarms; ROAR_FAIL_AT=n in the environment arms it at load).  tests/test_gpu_parity.py walks n over
+ * load / search / build scenarios and checks that every failure is reported and leaves no device memory behind. */
+int roar_debug_fail_device_alloc_at(int64_t n);
+
 /* Known-answer surface for NeighborPriorityQueue (include/efanna2e/neighbor.h:138-223): replays a scripted sequence on
  * the device with the queue routines of the search kernels -- ops[i] == 0: insert(ids[i], dists[i]) (:150-183), else
  * closest_unexpanded() if has_unexpanded_node() (:185-194) -- and returns the state after every op,

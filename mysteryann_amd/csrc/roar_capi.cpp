@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -69,6 +70,9 @@ int roar_rg_merge_rows(const uint32_t *grows, uint32_t Sg, const uint32_t *srows
                        uint64_t n, uint32_t M, void *stream);
 int roar_rg_copy_rows(const uint32_t *src, uint32_t Ssrc, uint32_t *dst, uint32_t Sdst, uint64_t n, void *stream);
 }
+extern "C" int roar_hub_build_rows(const uint32_t *adj, uint32_t S, uint64_t n, uint32_t *out, uint32_t Sh, uint32_t *indeg,
+                                   uint16_t *slot_of, unsigned long long *keys_a, unsigned long long *keys_b, void *sort_tmp,
+                                   size_t *sort_tmp_bytes, void *stream);  // roar_hub.hip
 extern "C" int roar_launch_queue_trace(uint32_t capacity, uint32_t n_ops, const uint8_t *ops, const uint32_t *ids,
                                        const float *dists, int form, uint32_t *snap, void *stream);
 extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim,
@@ -96,6 +100,25 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// Every device allocation of this file goes through here so that error paths can be exercised: the n-th allocation from
+// now fails with hipErrorOutOfMemory when armed (roar_debug_fail_device_alloc_at, or ROAR_FAIL_AT=n in the environment
+// when the library is loaded).  Unarmed it is hipMalloc.
+std::atomic<int64_t> g_fail_alloc_in{[] {
+    const char *v = getenv("ROAR_FAIL_AT");
+    return (int64_t)(v ? atoll(v) : 0);
+}()};
+hipError_t roar_dev_malloc(void **p, size_t bytes) {
+    if (g_fail_alloc_in.load(std::memory_order_relaxed) > 0 && g_fail_alloc_in.fetch_sub(1) == 1) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
+}
+template <typename T>
+hipError_t roar_dev_malloc(T **p, size_t bytes) {
+    return roar_dev_malloc(reinterpret_cast<void **>(p), bytes);
+}
 
 }  // namespace
 
@@ -291,7 +314,7 @@ int alloc_base(roar_index *idx, uint64_t n) {
     free_base(idx);
     free_tags(idx);
     idx->ld = idx->dim_pad;
-    HIP_TRY(hipMalloc((void **)&idx->base, (size_t)n * idx->ld * sizeof(float)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->base, (size_t)n * idx->ld * sizeof(float)));
     idx->base_owned = true;
     idx->n = n;
     return ROAR_OK;
@@ -323,9 +346,9 @@ int ensure_tags(roar_index *idx, uint32_t *slots_io) {
     if (idx->tags && idx->slots >= slots) return ROAR_OK;
     free_tags(idx);
     idx->tag_stride = stride;
-    HIP_TRY(hipMalloc((void **)&idx->tags, (size_t)slots * idx->tag_stride));
+    HIP_TRY(roar_dev_malloc((void **)&idx->tags, (size_t)slots * idx->tag_stride));
     HIP_TRY(hipMemset(idx->tags, 0, (size_t)slots * idx->tag_stride));
-    HIP_TRY(hipMalloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->epochs, (size_t)slots * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->epochs, 0, (size_t)slots * sizeof(uint32_t)));
     idx->slots = slots;
     return ROAR_OK;
@@ -348,9 +371,9 @@ int ensure_spill(roar_index *idx, uint32_t slots, bool *granted) {
     idx->spill_epochs = nullptr;
     idx->spill_slots = 0;
     idx->spill_stride = stride;
-    hipError_t e = hipMalloc((void **)&idx->spill, (size_t)slots * stride * 2);
+    hipError_t e = roar_dev_malloc((void **)&idx->spill, (size_t)slots * stride * 2);
     if (e == hipSuccess) e = hipMemset(idx->spill, 0, (size_t)slots * stride * 2);
-    if (e == hipSuccess) e = hipMalloc((void **)&idx->spill_epochs, (size_t)slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = roar_dev_malloc((void **)&idx->spill_epochs, (size_t)slots * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(idx->spill_epochs, 0, (size_t)slots * sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -378,9 +401,9 @@ int ensure_tags32(roar_index *idx, uint32_t *slots_io) {
     idx->epochs32 = nullptr;
     idx->slots32 = 0;
     idx->tag_stride32 = stride;
-    HIP_TRY(hipMalloc((void **)&idx->tags32, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->tags32, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->tags32, 0, (size_t)slots * idx->tag_stride32 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&idx->epochs32, (size_t)slots * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->epochs32, (size_t)slots * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->epochs32, 0, (size_t)slots * sizeof(uint32_t)));
     idx->slots32 = slots;
     return ROAR_OK;
@@ -412,7 +435,7 @@ int ensure_host_csr(roar_index *idx) {
 constexpr uint32_t LAUNCH_RING = 256;  // launch cells: more launches than this are never in flight on one index
 constexpr size_t ADJ_SLACK_WORDS = 256;  // a row read is up to 4 x 64 words from the row's first word
 
-// Hub-annotated adjacency (see RoarSearchParams::adj_hub).  Host pass over the device rows, once per graph: in-degrees,
+// Hub-annotated adjacency (see RoarSearchParams::adj_hub), built on the device (roar_hub.hip), once per graph: in-degrees,
 // the H = min(65 535, n) nodes with the most in-edges (ties to the smaller id) get bitmap slots 0..H-1, every row is
 // rewritten as [degree | hubs << 16][hub neighbours, in row order][the others, in row order][u16 slot per hub neighbour].
 // Within a hop the scan order cannot change the pool, so listing hubs first changes no result.
@@ -424,59 +447,31 @@ int ensure_hub_rows(roar_index *idx) {
         return ROAR_OK;
     }
     const uint64_t n = idx->gn;
-    const uint32_t S = idx->adj_stride;
     const uint32_t Sh = round_up(1 + idx->max_deg + (idx->max_deg + 1) / 2, 32);  // <= 256
-    std::vector<uint32_t> rows, hub, indeg, order;
-    std::vector<uint16_t> slot_of;
-    try {
-        rows.resize((size_t)n * S);
-        hub.assign((size_t)n * Sh + ADJ_SLACK_WORDS, 0u);
-        indeg.assign((size_t)n, 0u);
-        order.resize((size_t)n);
-        slot_of.assign((size_t)n, (uint16_t)0xFFFFu);
-    } catch (...) {
-        return fail(ROAR_ERR_DEVICE, "out of host memory for the hub pass");
-    }
-    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (S * 4));
-    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
-        const uint64_t cnt = std::min(chunk, n - r0);
-        HIP_TRY(hipMemcpy(rows.data() + r0 * S, idx->adj + r0 * S, (size_t)cnt * S * 4, hipMemcpyDeviceToHost));
-    }
-    for (uint64_t v = 0; v < n; ++v) {
-        const uint32_t *row = rows.data() + v * S;
-        for (uint32_t j = 0; j < row[0]; ++j) indeg[row[1 + j]]++;
-    }
-    const uint32_t H = (uint32_t)std::min<uint64_t>(65535, n);  // slot 0xFFFF means "no slot"
-    for (uint64_t v = 0; v < n; ++v) order[v] = (uint32_t)v;
-    auto more = [&](uint32_t a, uint32_t b) { return indeg[a] != indeg[b] ? indeg[a] > indeg[b] : a < b; };
-    if (H < n) std::nth_element(order.begin(), order.begin() + H, order.end(), more);
-    std::sort(order.begin(), order.begin() + H, more);
-    for (uint32_t s2 = 0; s2 < H; ++s2) slot_of[order[s2]] = (uint16_t)s2;
-    auto build = [&](uint64_t v0, uint64_t v1) {
-        for (uint64_t v = v0; v < v1; ++v) {
-            const uint32_t *row = rows.data() + v * S;
-            uint32_t *o = hub.data() + v * Sh;
-            const uint32_t deg = row[0];
-            uint32_t nh = 0;
-            for (uint32_t j = 0; j < deg; ++j)
-                if (slot_of[row[1 + j]] != 0xFFFFu) o[1 + nh++] = row[1 + j];
-            uint32_t w = nh;
-            for (uint32_t j = 0; j < deg; ++j)
-                if (slot_of[row[1 + j]] == 0xFFFFu) o[1 + w++] = row[1 + j];
-            o[0] = deg | (nh << 16);
-            uint16_t *sl = reinterpret_cast<uint16_t *>(o + 1 + deg);
-            for (uint32_t j = 0; j < nh; ++j) sl[j] = slot_of[o[1 + j]];
-        }
+    uint32_t *hub = nullptr, *indeg = nullptr;
+    uint16_t *slot_of = nullptr;
+    unsigned long long *ka = nullptr, *kb = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    auto bail = [&](hipError_t e, const char *what) {  // every failure leaves the index without hub rows, and nothing behind
+        (void)hipFree(hub), (void)hipFree(indeg), (void)hipFree(slot_of), (void)hipFree(ka), (void)hipFree(kb), (void)hipFree(tmp);
+        return fail(ROAR_ERR_DEVICE, "hub rows: %s: %s", what, hipGetErrorString(e));
     };
-    {
-        const unsigned T = n >= (1u << 18) ? 8u : 1u;
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(build, n * t / T, n * (t + 1) / T);
-        build(0, n / T);
-        for (auto &x : th) x.join();
-    }
-    HIP_TRY(hipMalloc((void **)&idx->adj_hub, hub.size() * 4));
-    HIP_TRY(hipMemcpy(idx->adj_hub, hub.data(), hub.size() * 4, hipMemcpyHostToDevice));
+    hipError_t e = (hipError_t)roar_hub_build_rows(nullptr, 0, n, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &tmp_bytes, nullptr);
+    if (e != hipSuccess) return bail(e, "sizing the sort");
+    const size_t hub_words = (size_t)n * Sh + ADJ_SLACK_WORDS;
+    if ((e = roar_dev_malloc((void **)&hub, hub_words * 4)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = roar_dev_malloc((void **)&indeg, (size_t)n * 4)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = roar_dev_malloc((void **)&slot_of, (size_t)n * 2)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = roar_dev_malloc((void **)&ka, (size_t)n * 8)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = roar_dev_malloc((void **)&kb, (size_t)n * 8)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = roar_dev_malloc(&tmp, tmp_bytes)) != hipSuccess) return bail(e, "out of device memory");
+    if ((e = hipMemset(hub, 0, hub_words * 4)) != hipSuccess) return bail(e, "memset");
+    e = (hipError_t)roar_hub_build_rows(idx->adj, idx->adj_stride, n, hub, Sh, indeg, slot_of, ka, kb, tmp, &tmp_bytes, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return bail(e, "kernels");
+    (void)hipFree(indeg), (void)hipFree(slot_of), (void)hipFree(ka), (void)hipFree(kb), (void)hipFree(tmp);
+    idx->adj_hub = hub;
     idx->hub_stride = Sh;
     idx->hub_state = 1;
     return ROAR_OK;
@@ -754,7 +749,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
             if (idx->prof_dev) (void)hipFree(idx->prof_dev);
             idx->prof_dev = nullptr;
             idx->prof_cap = 0;
-            HIP_TRY(hipMalloc((void **)&idx->prof_dev, (size_t)nq * 16 * sizeof(unsigned long long)));
+            HIP_TRY(roar_dev_malloc((void **)&idx->prof_dev, (size_t)nq * 16 * sizeof(unsigned long long)));
             idx->prof_cap = nq;
         }
         p.prof = idx->prof_dev;
@@ -781,7 +776,7 @@ int stage_queries(roar_index *idx, const float *queries, uint64_t nq, uint32_t q
         if (idx->out_pin) (void)hipHostFree(idx->out_pin);
         idx->out_dev = idx->out_pin = nullptr;
         idx->out_cap = 0;
-        HIP_TRY(hipMalloc((void **)&idx->out_dev, (size_t)owords * sizeof(uint32_t)));
+        HIP_TRY(roar_dev_malloc((void **)&idx->out_dev, (size_t)owords * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc((void **)&idx->out_pin, (size_t)owords * sizeof(uint32_t), hipHostMallocDefault));
         idx->out_cap = owords;
     }
@@ -904,8 +899,8 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         idx->n_cus = prop.multiProcessorCount;
-        HIP_TRY(hipMalloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&idx->ring, LAUNCH_RING * 4 * sizeof(uint32_t)));
+        HIP_TRY(roar_dev_malloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
+        HIP_TRY(roar_dev_malloc((void **)&idx->ring, LAUNCH_RING * 4 * sizeof(uint32_t)));
         HIP_TRY(hipMemset(idx->ring, 0, LAUNCH_RING * 4 * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&idx->ev0));
@@ -1062,7 +1057,7 @@ int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t 
     // rows start on 128-byte lines; 64 words of slack so that a 64-lane chunk read never leaves the buffer
     idx->adj_stride = round_up(max_deg + 1, 32);
     const size_t words = (size_t)n * idx->adj_stride + ADJ_SLACK_WORDS;
-    HIP_TRY(hipMalloc((void **)&idx->adj, words * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->adj, words * sizeof(uint32_t)));
     // Build rows in chunks.  A neighbour repeated inside one list is kept once (first occurrence):
     // the reference skips the repeat through its visited test (index_bipartite.cpp:2378), so the
     // search result and cmps are unchanged, and the device visited filter sees distinct ids per row.
@@ -1182,7 +1177,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     free_graph(idx);
     const uint64_t n = idx->n;
     const uint32_t S = round_up(max_degree + 1, 32);
-    HIP_TRY(hipMalloc((void **)&idx->adj, ((size_t)n * S + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->adj, ((size_t)n * S + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(idx->adj, 0, ((size_t)n * S + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
     idx->adj_stride = S;
     idx->gn = n;
@@ -1216,13 +1211,13 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
             return fail(ROAR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));                   \
         }                                                                                           \
     } while (0)
-    HIP_TRYC(hipMalloc((void **)&res_ids, (size_t)cap * K * 4));
-    HIP_TRYC(hipMalloc((void **)&res_d, (size_t)cap * K * 4));
-    HIP_TRYC(hipMalloc((void **)&indeg, (size_t)n * 4));
+    HIP_TRYC(roar_dev_malloc((void **)&res_ids, (size_t)cap * K * 4));
+    HIP_TRYC(roar_dev_malloc((void **)&res_d, (size_t)cap * K * 4));
+    HIP_TRYC(roar_dev_malloc((void **)&indeg, (size_t)n * 4));
     HIP_TRYC(hipMemset(indeg, 0, (size_t)n * 4));
-    HIP_TRYC(hipMalloc((void **)&base_deg, (size_t)n * 4));
-    HIP_TRYC(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
-    HIP_TRYC(hipMalloc((void **)&scratch, 16));
+    HIP_TRYC(roar_dev_malloc((void **)&base_deg, (size_t)n * 4));
+    HIP_TRYC(roar_dev_malloc((void **)&sums, idx->dim_pad * sizeof(float)));
+    HIP_TRYC(roar_dev_malloc((void **)&scratch, 16));
     {
         const uint64_t per_list = 2ull * std::max<uint64_t>(std::max<uint64_t>(K, M), 1);
         const int rc = roar_bk_ws_create(std::max<uint64_t>(cap * per_list, n), &ws);
@@ -1367,7 +1362,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
         const uint32_t S_new = round_up(idx->max_deg + 1, 32);
         if (S_new < S) {
             uint32_t *compact = nullptr;
-            HIP_TRYC(hipMalloc((void **)&compact, ((size_t)n * S_new + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
+            HIP_TRYC(roar_dev_malloc((void **)&compact, ((size_t)n * S_new + ADJ_SLACK_WORDS) * sizeof(uint32_t)));
             BK_TRY(roar_bk_restride(idx->adj, S, compact, S_new, n, nullptr));
             HIP_TRYC(hipMemsetAsync(compact + (size_t)n * S_new, 0, ADJ_SLACK_WORDS * sizeof(uint32_t), nullptr));
             HIP_TRYC(hipDeviceSynchronize());
@@ -1444,27 +1439,27 @@ int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint
             return fail(ROAR_ERR_DEVICE, "%s: %s", #call, hipGetErrorString((hipError_t)rc_)); \
         }                                                                                   \
     } while (0)
-    RG_HIP(hipMalloc((void **)&grows, ((size_t)n * Sg + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(roar_dev_malloc((void **)&grows, ((size_t)n * Sg + ADJ_SLACK_WORDS) * 4));
     RG_HIP(hipMemset(grows, 0, ((size_t)n * Sg + ADJ_SLACK_WORDS) * 4));
-    RG_HIP(hipMalloc((void **)&srows, ((size_t)n * Ss + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(roar_dev_malloc((void **)&srows, ((size_t)n * Ss + ADJ_SLACK_WORDS) * 4));
     RG_HIP(hipMemset(srows, 0, ((size_t)n * Ss + ADJ_SLACK_WORDS) * 4));
-    RG_HIP(hipMalloc((void **)&last, (size_t)n * 4));
+    RG_HIP(roar_dev_malloc((void **)&last, (size_t)n * 4));
     RG_HIP(hipMemset(last, 0, (size_t)n * 4));
     const uint64_t max_lists = std::max<uint64_t>(std::max<uint64_t>(batch_lists, batch_nodes), std::min<uint64_t>(n, 1u << 20));
-    RG_HIP(hipMalloc((void **)&out, (size_t)max_lists * M * 4));
-    RG_HIP(hipMalloc((void **)&cnt, (size_t)max_lists * 4));
-    RG_HIP(hipMalloc((void **)&props_a, (size_t)max_props * 8));
-    RG_HIP(hipMalloc((void **)&props_b, (size_t)max_props * 8));
-    RG_HIP(hipMalloc((void **)&heads, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
-    RG_HIP(hipMalloc((void **)&heads_sorted, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
-    RG_HIP(hipMalloc((void **)&nheads_dev, 4));
+    RG_HIP(roar_dev_malloc((void **)&out, (size_t)max_lists * M * 4));
+    RG_HIP(roar_dev_malloc((void **)&cnt, (size_t)max_lists * 4));
+    RG_HIP(roar_dev_malloc((void **)&props_a, (size_t)max_props * 8));
+    RG_HIP(roar_dev_malloc((void **)&props_b, (size_t)max_props * 8));
+    RG_HIP(roar_dev_malloc((void **)&heads, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
+    RG_HIP(roar_dev_malloc((void **)&heads_sorted, (size_t)std::min<uint64_t>(max_props, n) * 4 + 64));
+    RG_HIP(roar_dev_malloc((void **)&nheads_dev, 4));
     RG_TRY(roar_rg_sort_tmp_bytes(max_props, &sort_tmp_bytes));
-    RG_HIP(hipMalloc(&sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16));
-    RG_HIP(hipMalloc((void **)&res_ids, (size_t)batch_nodes * Lp * 4));
-    RG_HIP(hipMalloc((void **)&res_d, (size_t)batch_nodes * Lp * 4));
-    RG_HIP(hipMalloc((void **)&keyscratch, (size_t)scratch_waves * Lp * 8));
-    RG_HIP(hipMalloc((void **)&sums, idx->dim_pad * sizeof(float)));
-    RG_HIP(hipMalloc((void **)&scratch, 16));
+    RG_HIP(roar_dev_malloc(&sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16));
+    RG_HIP(roar_dev_malloc((void **)&res_ids, (size_t)batch_nodes * Lp * 4));
+    RG_HIP(roar_dev_malloc((void **)&res_d, (size_t)batch_nodes * Lp * 4));
+    RG_HIP(roar_dev_malloc((void **)&keyscratch, (size_t)scratch_waves * Lp * 8));
+    RG_HIP(roar_dev_malloc((void **)&sums, idx->dim_pad * sizeof(float)));
+    RG_HIP(roar_dev_malloc((void **)&scratch, 16));
 
     // CalculateProjectionep (:2004-2041)
     RG_TRY(roar_bk_entry_point(idx->base, idx->ld, idx->dim_pad, n, sums, (unsigned long long *)scratch, nullptr));
@@ -1526,7 +1521,7 @@ int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint
         RG_TRY(roar_rg_set_rows(srows, Ss, nullptr, 0, c, 0, (uint32_t)v0, 0, nullptr, out, cnt, M, props_a, nullptr));
     }
     // ---- merge (:1262-1275)
-    RG_HIP(hipMalloc((void **)&final_adj, ((size_t)n * Sf + ADJ_SLACK_WORDS) * 4));
+    RG_HIP(roar_dev_malloc((void **)&final_adj, ((size_t)n * Sf + ADJ_SLACK_WORDS) * 4));
     RG_HIP(hipMemset(final_adj, 0, ((size_t)n * Sf + ADJ_SLACK_WORDS) * 4));
     RG_TRY(roar_rg_merge_rows(grows, Sg, srows, Ss, final_adj, Sf, n, M, nullptr));
     RG_TRY(roar_bk_degree_stats(final_adj, Sf, n, (unsigned long long *)scratch, scratch + 2, nullptr));
@@ -1556,7 +1551,7 @@ int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_
     int e = use_device(idx);
     if (e) return e;
     uint32_t *lists_dev = nullptr;
-    HIP_TRY(hipMalloc((void **)&lists_dev, (size_t)n_learn * K * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&lists_dev, (size_t)n_learn * K * sizeof(uint32_t)));
     hipError_t he = hipMemcpy(lists_dev, learn_knn, (size_t)n_learn * K * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (he != hipSuccess) {
         (void)hipFree(lists_dev);
@@ -1826,7 +1821,7 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
     if (he != hipSuccess) return bail(fail(ROAR_ERR_DEVICE, "copy of the base rows to device %d failed: %s", device, hipGetErrorString(he)));
     if (src->adj) {
         const size_t words = (size_t)src->gn * src->adj_stride + ADJ_SLACK_WORDS;
-        if (hipMalloc((void **)&dst->adj, words * sizeof(uint32_t)) != hipSuccess)
+        if (roar_dev_malloc((void **)&dst->adj, words * sizeof(uint32_t)) != hipSuccess)
             return bail(fail(ROAR_ERR_DEVICE, "out of device memory for the graph replica"));
         he = hipMemcpyPeer(dst->adj, dst->device, src->adj, src->device, words * sizeof(uint32_t));
         if (he != hipSuccess) return bail(fail(ROAR_ERR_DEVICE, "copy of the graph to device %d failed: %s", device, hipGetErrorString(he)));
@@ -1988,8 +1983,8 @@ int roar_set_bipartite_csr(roar_index *idx, uint64_t n_total, const uint64_t *of
         free_bipartite(idx);
         return e;
     }
-    HIP_TRY(hipMalloc((void **)&idx->bp_off, (size_t)(n_total + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&idx->bp_nbrs, (size_t)(ne + 64) * sizeof(uint32_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->bp_off, (size_t)(n_total + 1) * sizeof(uint64_t)));
+    HIP_TRY(roar_dev_malloc((void **)&idx->bp_nbrs, (size_t)(ne + 64) * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(idx->bp_off, offsets, (size_t)(n_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (ne) HIP_TRY(hipMemcpy(idx->bp_nbrs, nbrs, (size_t)ne * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(idx->bp_nbrs + ne, 0, 64 * sizeof(uint32_t)));
@@ -2168,7 +2163,7 @@ int roar_search_bipartite_batch(roar_index *idx, const float *queries, uint64_t 
     if (idx->init_cap < nq * n_init) {
         if (idx->init_dev) (void)hipFree(idx->init_dev);
         idx->init_dev = nullptr;
-        HIP_TRY(hipMalloc((void **)&idx->init_dev, (size_t)nq * n_init * sizeof(uint32_t)));
+        HIP_TRY(roar_dev_malloc((void **)&idx->init_dev, (size_t)nq * n_init * sizeof(uint32_t)));
         idx->init_cap = nq * n_init;
     }
     HIP_TRY(hipMemcpyAsync(idx->init_dev, init_ids, (size_t)nq * n_init * sizeof(uint32_t), hipMemcpyHostToDevice, idx->stream));
@@ -2217,9 +2212,9 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
         uint32_t *&i;
         ~Free() { (void)hipFree(q), (void)hipFree(o), (void)hipFree(i); }
     } free_all{q_dev, o_dev, i_dev};
-    HIP_TRY(hipMalloc((void **)&q_dev, buf.size() * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&i_dev, (size_t)nq * m * 4));
-    HIP_TRY(hipMalloc((void **)&o_dev, (size_t)nq * m * 4));
+    HIP_TRY(roar_dev_malloc((void **)&q_dev, buf.size() * sizeof(float)));
+    HIP_TRY(roar_dev_malloc((void **)&i_dev, (size_t)nq * m * 4));
+    HIP_TRY(roar_dev_malloc((void **)&o_dev, (size_t)nq * m * 4));
     HIP_TRY(hipMemcpy(q_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(i_dev, ids, (size_t)nq * m * 4, hipMemcpyHostToDevice));
     RoarDistParams p;
@@ -2263,17 +2258,17 @@ int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq
         (void)hipFree(cand); (void)hipFree(cursor); (void)hipFree(tau); (void)hipFree(bnorm); (void)hipFree(ovf);
     };
     {
-        hipError_t he = hipMalloc(&cursor, chunk * 4);
-        if (he == hipSuccess) he = hipMalloc(&tau, chunk * 4);
-        if (he == hipSuccess) he = hipMalloc(&ovf, 4);
-        if (he == hipSuccess && !idx->ip) he = hipMalloc(&bnorm, idx->n * 4);
+        hipError_t he = roar_dev_malloc(&cursor, chunk * 4);
+        if (he == hipSuccess) he = roar_dev_malloc(&tau, chunk * 4);
+        if (he == hipSuccess) he = roar_dev_malloc(&ovf, 4);
+        if (he == hipSuccess && !idx->ip) he = roar_dev_malloc(&bnorm, idx->n * 4);
         if (he != hipSuccess) {
             cleanup();
             return fail(ROAR_ERR_DEVICE, "out of device memory for the exact kNN workspaces: %s", hipGetErrorString(he));
         }
     }
     for (;;) {
-        if (hipMalloc(&cand, chunk * cap * 8) != hipSuccess) {
+        if (roar_dev_malloc(&cand, chunk * cap * 8) != hipSuccess) {
             cleanup();
             return fail(ROAR_ERR_DEVICE, "out of device memory for the kNN candidate lists");
         }
@@ -2322,9 +2317,9 @@ int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     }
     auto cleanup = [&]() { (void)hipFree(q_dev); (void)hipFree(i_dev); (void)hipFree(d_dev); };
     {
-        hipError_t he = hipMalloc((void **)&q_dev, buf.size() * sizeof(float));
-        if (he == hipSuccess) he = hipMalloc((void **)&i_dev, (size_t)chunk * k * 4);
-        if (he == hipSuccess) he = hipMalloc((void **)&d_dev, (size_t)chunk * k * 4);
+        hipError_t he = roar_dev_malloc((void **)&q_dev, buf.size() * sizeof(float));
+        if (he == hipSuccess) he = roar_dev_malloc((void **)&i_dev, (size_t)chunk * k * 4);
+        if (he == hipSuccess) he = roar_dev_malloc((void **)&d_dev, (size_t)chunk * k * 4);
         if (he != hipSuccess) {
             cleanup();
             return fail(ROAR_ERR_DEVICE, "out of device memory for the exact kNN staging blocks: %s", hipGetErrorString(he));
@@ -2389,10 +2384,10 @@ int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_
     uint32_t *d_ids = nullptr, *d_snap = nullptr;
     float *d_d = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_ops); (void)hipFree(d_ids); (void)hipFree(d_d); (void)hipFree(d_snap); };
-    hipError_t e = hipMalloc((void **)&d_ops, n_ops);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_ids, (size_t)n_ops * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_d, (size_t)n_ops * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_snap, (size_t)n_ops * row * 4);
+    hipError_t e = roar_dev_malloc((void **)&d_ops, n_ops);
+    if (e == hipSuccess) e = roar_dev_malloc((void **)&d_ids, (size_t)n_ops * 4);
+    if (e == hipSuccess) e = roar_dev_malloc((void **)&d_d, (size_t)n_ops * 4);
+    if (e == hipSuccess) e = roar_dev_malloc((void **)&d_snap, (size_t)n_ops * row * 4);
     if (e == hipSuccess) e = hipMemcpy(d_ops, ops, n_ops, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_ids, ids, (size_t)n_ops * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, dists, (size_t)n_ops * 4, hipMemcpyHostToDevice);
@@ -2401,6 +2396,11 @@ int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_
     if (e == hipSuccess) e = hipMemcpy(snap, d_snap, (size_t)n_ops * row * 4, hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return fail(ROAR_ERR_DEVICE, "queue trace failed: %s", hipGetErrorString(e));
+    return ROAR_OK;
+}
+
+int roar_debug_fail_device_alloc_at(int64_t n) {
+    g_fail_alloc_in.store(n > 0 ? n : 0);
     return ROAR_OK;
 }
 
@@ -2487,7 +2487,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
         if (!idx->graph_hash_valid) {
             HIP_TRY(hipSetDevice(idx->device));
             unsigned long long *h_dev = nullptr, h = 0;
-            HIP_TRY(hipMalloc((void **)&h_dev, 8));
+            HIP_TRY(roar_dev_malloc((void **)&h_dev, 8));
             int rc = roar_bk_graph_hash(idx->adj, idx->adj_stride, idx->gn, idx->ep, h_dev, nullptr);
             hipError_t he = rc == 0 ? hipMemcpy(&h, h_dev, 8, hipMemcpyDeviceToHost) : (hipError_t)rc;
             (void)hipFree(h_dev);

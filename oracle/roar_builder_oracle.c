@@ -113,7 +113,7 @@ static uint32_t prune_bisearch(const ctx *c, const bn *pool, uint32_t np, uint32
  * leading zero entries, no back-fill) */
 static uint32_t prune_reverse(const ctx *c, uint32_t src, const uint32_t *list, uint32_t nl, int internal, uint32_t *res) {
     bn *q = (bn *)calloc((size_t)nl * 2 + 1, sizeof(bn));
-    uint32_t nq = internal ? nl : 0, nres = 0; /* :1438: nl zero-initialised entries first */
+    uint32_t nq = (internal && !(c->flags & 16)) ? nl : 0, nres = 0; /* :1438: nl zero-initialised entries first (flags bit 4: without them) */
     for (uint32_t i = 0; i < nl; ++i) {
         int seen = 0;
         for (uint32_t j = 0; j < nq; ++j) if (q[j].id == list[i]) { seen = 1; break; }

@@ -69,6 +69,20 @@ for L in args.Ls:
     out["curve"][str(L)] = {"recall_at_10": float(oracle.recall(r["ids"], gt, 10)), "avg_cmps": float(r["cmps"].mean()),
                             "avg_hops": float(r["hops"].mean())}
     print(L, out["curve"][str(L)], flush=True)
+if args.survey_probe:
+    # the `std::vector<Neighbor> prune_queue(pruned_list.size())` quirk of :1438 (the work list of the supply pass's reverse
+    # prune starts with size() zero entries: id 0, distance 0): the same build without it, to see whether it moves the curve
+    t0 = time.time()
+    ep2, off2, nbrs2 = oracle.build_roargraph(base, knn, 1, 100, 35, 500, flags=16)
+    deg2 = np.diff(off2.astype(np.int64))
+    out["without_the_prune_queue_quirk"] = {"ep": int(ep2), "avg_degree": float(deg2.mean()), "max_degree": int(deg2.max()),
+                                            "edges_to_node_0": int((nbrs2 == 0).sum()), "curve": {}}
+    out["edges_to_node_0"] = int((nbrs == 0).sum())
+    for L in args.Ls:
+        r = oracle.search_batch(base, off2, nbrs2, ep2, q, 10, L, 1, threads=args.threads)
+        out["without_the_prune_queue_quirk"]["curve"][str(L)] = {
+            "recall_at_10": float(oracle.recall(r["ids"], gt, 10)), "avg_cmps": float(r["cmps"].mean()), "avg_hops": float(r["hops"].mean())}
+    print(f"without the :1438 quirk ({time.time() - t0:.0f}s):", out["without_the_prune_queue_quirk"], flush=True)
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden", f"{args.name}_{n}.json")
 json.dump(out, open(path, "w"), indent=1)
 print("written", path)

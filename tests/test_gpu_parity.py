@@ -952,6 +952,46 @@ def test_pageable_host_path_survives_a_blocking_launch(golden_dir):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_device_builder_matches_the_survey_probe_of_the_compiled_reference(golden_dir, built_lib):
+    """roar_build_roargraph_device on the survey's probe recipe (50 000 points, canonical parameters) against BOTH the
+    figures of the compiled reference builder (the only real-reference builder numbers there are)
+    and the restated builder's (tests/golden/builder_probe_50000.json): average degree within 5 %, longest row 70, recall@10
+    within 0.02 of the survey's at L_pq = 20 and >= 0.99 at 100, hops within 3 %, distance evaluations within 10 %."""
+    import json
+
+    import torch
+
+    import oracle
+    from mysteryann_amd import index as mi, synth
+
+    Y = json.load(open(os.path.join(golden_dir, "builder_probe_50000.json")))
+    S = Y["survey_probe_of_the_compiled_reference"]
+    n, nq = Y["n"], Y["nq"]
+    base, q, learn = synth.t2i_numpy(n, nq, 200, seed=Y["seed"], n_learn=Y["n_learn"])
+    idx = mi.IndexBipartite(200, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    lists, _ = idx.ExactKnnDevice(torch.from_numpy(learn).cuda(), 100, want_dists=False)
+    p = mi.Parameters()
+    p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 500)
+    idx.BuildRoarGraphDevice(lists, p)
+    assert idx.info("ep") == Y["ep"]
+    avg = idx.info("nedges") / n
+    assert abs(avg - S["avg_degree"]) <= 0.05 * S["avg_degree"] and abs(avg - Y["avg_degree"]) <= 0.03 * Y["avg_degree"], avg
+    assert idx.info("max_degree") == S["max_degree"]
+    gt = idx.ExactKnnDevice(torch.from_numpy(q).cuda(), 10, want_dists=False)[0].cpu().numpy().view(np.uint32)
+    idx.set_option("visited_mode", 0)
+    for L in (10, 20, 50, 100, 200, 500):
+        r = idx.SearchRoarGraphBatch(q, 10, L)
+        rec, hops, cmps = oracle.recall(r["ids"], gt, 10), float(r["hops"].mean()), float(r["cmps"].mean())
+        assert abs(hops - S["avg_hops"][str(L)]) <= 0.03 * S["avg_hops"][str(L)], (L, hops)
+        assert abs(cmps - S["avg_cmps"][str(L)]) <= 0.10 * S["avg_cmps"][str(L)], (L, cmps)
+        assert abs(cmps - Y["curve"][str(L)]["avg_cmps"]) <= 0.05 * Y["curve"][str(L)]["avg_cmps"], (L, cmps)
+        if str(L) in S["recall_at_10"]:
+            assert abs(rec - S["recall_at_10"][str(L)]) <= 0.02, (L, rec)
+        assert abs(rec - Y["curve"][str(L)]["recall_at_10"]) <= 0.012, (L, rec)
+    idx.close()
+
+
 def _yardsticks():
     import glob
 

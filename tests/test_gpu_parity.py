@@ -992,6 +992,67 @@ def test_device_builder_matches_the_survey_probe_of_the_compiled_reference(golde
     idx.close()
 
 
+def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib):
+    """Fault injection (roar_debug_fail_device_alloc_at: the n-th device allocation of the library fails as if HBM were
+    exhausted), n = 1, 2, ... over a scenario that loads, searches in every visited form (spill lists, tag pools, hub rows
+    built on the device), scores explicit ids, runs the exact-kNN generator and makes a replica: every failure comes back as
+    ROAR_ERR_DEVICE through the C ABI, and after the objects are destroyed the device's free memory is back where it was
+    (hipMemGetInfo) -- round 2 leaked the staging blocks of roar_distances / roar_exact_knn and a half-made replica."""
+    import torch
+
+    from mysteryann_amd import capi
+    from mysteryann_amd import index as mi
+
+    lib = capi.lib()
+    n, d, nq = 4000, 200, 24
+    base, q, off, nbrs = _random_case(n, d, nq, 1, seed=31, maxdeg=40)
+    ids = np.random.default_rng(1).integers(0, n, (nq, 7)).astype(np.uint32)
+
+    def scenario():
+        made = []
+        try:
+            idx = mi.IndexBipartite(d, n, 1, None)
+            made.append(idx)
+            idx.SetBaseData(base)
+            idx.SetProjectionGraph(5, off, nbrs)
+            for mode, hub, L in ((1, 1, 50), (0, 1, 50), (1, 2, 120), (3, 1, 300)):
+                idx.set_option("visited_mode", mode)
+                idx.set_option("hub_mode", hub)
+                idx.SearchRoarGraphBatch(q, K, L)
+            idx.Distances(q, ids)
+            kid = np.zeros((nq, 5), np.uint32)
+            capi.check(lib.roar_exact_knn(idx._h, capi.f32p(q), nq, d, 5, capi.u32p(kid), None))
+            rep = idx.Clone(0)
+            made.append(rep)
+            mi.IndexBipartite.SearchRoarGraphBatchMulti([idx, rep], q, K, 40)
+        finally:
+            for x in made:
+                x.close()
+
+    scenario()  # warm: code objects, runtime pools
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    failures = 0
+    for nth in range(1, 200):
+        lib.roar_debug_fail_device_alloc_at(nth)
+        try:
+            scenario()
+            completed = True
+        except mi.RoarError as e:
+            completed = False
+            failures += 1
+            assert e.code == capi.ERR_DEVICE, (nth, e)
+        finally:
+            lib.roar_debug_fail_device_alloc_at(0)
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        assert abs(free - free0) <= (4 << 20), (nth, free0 - free)
+        if completed:
+            break
+    assert failures >= 20, failures  # the scenario makes a few dozen device allocations
+    scenario()  # and the library still works
+
+
 def _yardsticks():
     import glob
 

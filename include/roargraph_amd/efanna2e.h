@@ -385,5 +385,55 @@ class IndexBipartite {
     uint32_t knn_n_ = 0, knn_k_ = 0;
 };
 
+// New (BASELINE configs[4]): the base set cut into contiguous id ranges, one RoarGraph per range
+// (local ids), shard s on HIP device devices[s].  Same member names as IndexBipartite, with the shard number in front
+// where a file belongs to one shard; SearchRoarGraphBatch runs every query on every shard and returns the merge of the
+// per-shard lists (global ids) after ONE RCCL all-gather (roar_search_batch_sharded).
+class ShardedIndexBipartite {
+   public:
+    ShardedIndexBipartite(const size_t dimension, Metric m, const std::vector<int> &devices) : dimension_(dimension) {
+        if (m == COSINE) need_normalize = true;
+        check(roar_sharded_create(&h_, (uint32_t)dimension, (int)m, devices.data(), (uint32_t)devices.size()));
+        n_shards_ = devices.size();
+    }
+    ~ShardedIndexBipartite() {
+        if (h_) roar_sharded_destroy(h_);
+    }
+    ShardedIndexBipartite(const ShardedIndexBipartite &) = delete;
+    ShardedIndexBipartite &operator=(const ShardedIndexBipartite &) = delete;
+    size_t NumShards() const { return n_shards_; }
+    void LoadSearchNeededData(size_t s, const char *base_file) { check(roar_load_base_fbin(shard(s), base_file)); }
+    void LoadProjectionGraph(size_t s, const char *filename) { check(roar_load_graph_file(shard(s), filename)); }
+    void SetIdBase(size_t s, uint64_t first_global_id) { check(roar_sharded_set_id_base(h_, (uint32_t)s, first_global_id)); }
+    void SetOption(const char *key, int64_t v) {
+        for (size_t s = 0; s < n_shards_; ++s) check(roar_set_option(shard(s), key, v));
+    }
+    void SearchRoarGraphBatch(const float *queries, size_t nq, size_t k, uint32_t L_pq, unsigned *ids, float *dists,
+                              uint32_t *cmps, uint32_t *hops) {
+        check(roar_search_batch_sharded(h_, queries, nq, (uint32_t)dimension_, (uint32_t)k, L_pq, ids, dists, cmps, hops));
+    }
+    int64_t Info(const char *key) {
+        int64_t v = 0;
+        check(roar_sharded_info(h_, key, &v));
+        return v;
+    }
+    roar_index *shard(size_t s) {
+        roar_index *x = roar_sharded_shard(h_, (uint32_t)s);
+        if (!x) throw std::invalid_argument(roar_last_error());
+        return x;
+    }
+    bool need_normalize = false;
+
+   private:
+    static void check(int rc) {
+        if (rc == ROAR_OK) return;
+        const char *msg = roar_last_error();
+        if (rc == ROAR_ERR_ARG) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
+    }
+    size_t dimension_, n_shards_ = 0;
+    roar_sharded *h_ = nullptr;
+};
+
 }  // namespace efanna2e
 #endif

@@ -73,7 +73,11 @@ static void usage() {
                  "  --device <ordinal>\n"
                  "  --gpus <g>                   index replicated on devices device .. device + g - 1, the query block split by\n"
                  "                               query over them (no collective); 0 = every visible device; default 1\n"
-                 "  --devices <d0,d1,...>        explicit replica placement (a device may repeat); overrides --gpus\n";
+                 "  --devices <d0,d1,...>        explicit replica placement (a device may repeat); overrides --gpus\n"
+                 "  --shards <d0,d1,...>         index-sharded configuration: --base_data_path and --projection_index_save_path are\n"
+                 "                               comma separated lists, one file per shard (contiguous id ranges, local ids);\n"
+                 "                               shard s lives on device ds; every query is searched on every shard, the per-shard\n"
+                 "                               lists meet in one RCCL all-gather and are merged (ids reported are global)\n";
 }
 
 int main(int argc, char **argv) {
@@ -84,8 +88,28 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> L_vec;
     uint32_t num_threads = omp_get_num_procs(), k = 1;
     int device = 0, gpus = 1;
-    std::vector<int> device_list;
+    std::vector<int> device_list, shard_devices;
     bool per_query = false;
+    auto split_ints = [](const std::string &v) {
+        std::vector<int> out;
+        for (size_t p0 = 0; p0 <= v.size();) {
+            size_t p1 = v.find(',', p0);
+            if (p1 == std::string::npos) p1 = v.size();
+            out.push_back(std::stoi(v.substr(p0, p1 - p0)));
+            p0 = p1 + 1;
+        }
+        return out;
+    };
+    auto split_names = [](const std::string &v) {
+        std::vector<std::string> out;
+        for (size_t p0 = 0; p0 <= v.size();) {
+            size_t p1 = v.find(',', p0);
+            if (p1 == std::string::npos) p1 = v.size();
+            out.push_back(v.substr(p0, p1 - p0));
+            p0 = p1 + 1;
+        }
+        return out;
+    };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string {
@@ -121,6 +145,7 @@ int main(int argc, char **argv) {
             }
             if (!device_list.empty()) device = device_list[0];
         }
+        else if (a == "--shards") shard_devices = split_ints(next());
         else if (a == "--visited") visited = next();
         else if (a == "--per_query") per_query = true;
         else if (a == "--rderr") want_rderr = true;
@@ -145,8 +170,8 @@ int main(int argc, char **argv) {
         return -1;
     }
     try {
-        uint32_t base_num, base_dim;
-        efanna2e::load_meta<float>(base_data_file.c_str(), base_num, base_dim);
+        uint32_t base_num = 0, base_dim = 0;
+        if (shard_devices.empty()) efanna2e::load_meta<float>(base_data_file.c_str(), base_num, base_dim);
         efanna2e::Parameters parameters;
         parameters.Set<uint32_t>("num_threads", num_threads);
         omp_set_num_threads(num_threads);
@@ -179,6 +204,57 @@ int main(int argc, char **argv) {
         } else {
             std::cout << "Unknown distance type: " << dist << std::endl;
             return -1;
+        }
+        if (!shard_devices.empty()) {
+            // ---- index-sharded run: same loop and CSV as below, one ShardedIndexBipartite instead of one IndexBipartite
+            const std::vector<std::string> bases = split_names(base_data_file), graphs = split_names(projection_index_save_file);
+            if (bases.size() != shard_devices.size() || graphs.size() != shard_devices.size()) {
+                std::cerr << "--shards names " << shard_devices.size() << " devices: give as many base files and index files" << std::endl;
+                return -1;
+            }
+            efanna2e::ShardedIndexBipartite sharded(q_dim, dist_metric, shard_devices);
+            for (size_t s2 = 0; s2 < bases.size(); ++s2) {
+                sharded.LoadSearchNeededData(s2, bases[s2].c_str());
+                std::cout << "Load graph index: " << graphs[s2] << " (shard " << s2 << ", device " << shard_devices[s2] << ")" << std::endl;
+                sharded.LoadProjectionGraph(s2, graphs[s2].c_str());
+            }
+            if (sharded.need_normalize)
+                for (uint32_t i = 0; i < q_pts; i++) efanna2e::normalize<float>(aligned_query_data + (size_t)i * q_dim, q_dim);
+            sharded.SetOption("visited_mode", visited == "exact" ? ROAR_VISITED_EXACT : visited == "lds" ? ROAR_VISITED_LDS : ROAR_VISITED_AUTO);
+            std::cout << "Index sharded " << sharded.NumShards() << "-way over " << sharded.Info("ranks") << " device(s)" << std::endl;
+            std::cout << "k: " << k << std::endl;
+            std::vector<uint32_t> res((size_t)q_pts * k, 0), cmps_vec(q_pts, 0), hops_vec(q_pts, 0);
+            std::vector<float> res_d((size_t)q_pts * k, 0.f);
+            std::ofstream evaluation_out;
+            if (!evaluation_save_path.empty()) evaluation_out.open(evaluation_save_path, std::ios::out);
+            std::cout << "L_pq\t\tQPS\t\t\tavg_visited\tmean_latency\trecall@" << k << "\tavg_hops" << std::endl;
+            for (uint32_t L_pq : L_vec) {
+                if (k > L_pq) {
+                    std::cout << "L_pq must greater or equal than k" << std::endl;
+                    exit(1);
+                }
+                sharded.SearchRoarGraphBatch(aligned_query_data, std::min<uint32_t>(100, q_pts), k, L_pq, res.data(), res_d.data(),
+                                             cmps_vec.data(), hops_vec.data());  // warm-up, :198-200
+                auto start = std::chrono::high_resolution_clock::now();
+                sharded.SearchRoarGraphBatch(aligned_query_data, q_pts, k, L_pq, res.data(), res_d.data(), cmps_vec.data(), hops_vec.data());
+                auto end = std::chrono::high_resolution_clock::now();
+                double diff_ms = std::chrono::duration_cast<std::chrono::microseconds>(end - start).count() / 1000.0;
+                float qps = (float)((double)q_pts / (diff_ms / 1000.0));
+                float recall = ComputeRecall(q_pts, k, gt_dim, res.data(), gt_ids);
+                double avg_cmps = 0, avg_hops = 0;
+                for (size_t i = 0; i < q_pts; ++i) avg_cmps += cmps_vec[i], avg_hops += hops_vec[i];
+                avg_cmps /= q_pts, avg_hops /= q_pts;
+                std::cout << L_pq << "\t\t" << qps << "\t\t" << (float)avg_cmps << "\t\t" << (float)(diff_ms / q_pts) << "\t\t" << recall
+                          << "\t\t" << (float)avg_hops << std::endl;
+                if (evaluation_out.is_open())
+                    evaluation_out << L_pq << "," << qps << "," << (float)avg_cmps << "," << (float)(diff_ms / q_pts) << "," << recall << ","
+                                   << (float)avg_hops << std::endl;
+            }
+            if (pinned) efanna2e::unpin_block(aligned_query_data);
+            free(aligned_query_data);
+            delete[] gt_ids;
+            delete[] gt_dists;
+            return 0;
         }
         {
             std::ifstream probe(projection_index_save_file, std::ios::binary);

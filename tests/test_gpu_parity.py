@@ -1169,6 +1169,56 @@ def test_cpp_harness_end_to_end_on_files(tmp_path, built_lib):
             assert abs(float(r[4]) - oracle.recall(o["ids"], gt_i, 10)) < 1e-6
 
 
+def test_cpp_harness_index_sharded_on_files(tmp_path, built_lib):
+    """BASELINE configs[4] through the C++ harness: `--shards 0,0`, one base file and one index file per shard (local
+    ids), every query on every shard, per-shard lists all-gathered (RCCL, one rank here) and merged.  The CSV row must
+    carry the recall of the merged oracle lists and the cmps / hops summed over the shards."""
+    import subprocess
+
+    import oracle
+    from mysteryann_amd import fileio, synth
+    from tests.golden import small_builder as sb
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "mysteryann_amd", "csrc", "test_search_roargraph")
+    n, nq, d = 6000, 150, 200
+    base, q, learn = synth.t2i_numpy(n, nq, d, seed=6, n_learn=3000)
+    gt_i, gt_d = sb.exact_knn(q, base, 100, 1)
+    fileio.write_fbin(str(tmp_path / "query.fbin"), q)
+    fileio.write_gt(str(tmp_path / "gt.ibin"), gt_i, gt_d)
+    bases, graphs, per = [], [], []
+    for s_, (lo, hi) in enumerate(((0, 2500), (2500, 6000))):  # ragged shards
+        ep, adj = sb.build_roar_like(base[lo:hi], learn, 1, M_sq=24, M=12)
+        bases.append(str(tmp_path / f"base{s_}.fbin"))
+        graphs.append(str(tmp_path / f"roar{s_}.index"))
+        fileio.write_fbin(bases[-1], base[lo:hi])
+        fileio.write_graph(graphs[-1], ep, adj)
+        per.append((lo, ep) + sb.to_csr(adj))
+    csv = str(tmp_path / "eval.csv")
+    out = subprocess.run([exe, "--data_type", "float", "--dist", "ip", "--base_data_path", ",".join(bases), "--query_path",
+                          str(tmp_path / "query.fbin"), "--gt_path", str(tmp_path / "gt.ibin"), "--projection_index_save_path",
+                          ",".join(graphs), "--L_pq", "20", "60", "--k", "10", "--evaluation_save_path", csv, "--shards", "0,0",
+                          "--visited", "exact"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "Index sharded 2-way over 1 device(s)" in out.stdout
+    rows = [r.split(",") for r in open(csv).read().strip().splitlines()]
+    assert [int(r[0]) for r in rows] == [20, 60]
+    for r, L in zip(rows, (20, 60)):
+        oi, od, cm, hp = [], [], 0, 0
+        for lo, ep, off, nbrs in per:
+            hi = lo + len(off) - 1
+            o = oracle.search_batch(base[lo:hi], off, nbrs, ep, q, 10, L, 1)
+            oi.append(o["ids"] + np.uint32(lo)), od.append(o["dists"])
+            cm, hp = cm + o["cmps"].astype(np.int64), hp + o["hops"].astype(np.int64)
+        merged = np.zeros((nq, 10), np.uint32)
+        for qi in range(nq):
+            ci, cd = np.concatenate([x[qi] for x in oi]), np.concatenate([x[qi] for x in od])
+            merged[qi] = ci[np.lexsort((ci, cd))[:10]]
+        assert abs(float(r[4]) - oracle.recall(merged, gt_i, 10)) < 1e-6
+        assert abs(float(r[2]) - cm.mean()) < 2e-4 * cm.mean() + 1e-2
+        assert abs(float(r[5]) - hp.mean()) < 2e-4 * hp.mean() + 1e-3
+
+
 @pytest.mark.parametrize("metric", [1, 0])
 def test_builder_prune_kernel_matches_restated_prune_rule(metric, built_lib):
     """The builder's occlusion-prune kernel against the CPU restatement of PruneBiSearchBaseGetBase

@@ -127,7 +127,10 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--L", type=int, default=0, help="0 = smallest L_pq of the reference sweep with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.9)
-    ap.add_argument("--visited", default="auto", choices=["auto", "lds", "exact"])
+    ap.add_argument("--visited", default="auto", choices=["auto", "lds", "exact", "forgetful"],
+                    help="visited-set form: auto (the fastest per L_pq: the forgetful on-chip table, HBM tags for the longest pools), "
+                         "lds (on-chip table, exact: full sets spill to HBM), forgetful (on-chip table, a full set overwrites), "
+                         "exact (HBM tags only)")
     ap.add_argument("--build-M", type=int, default=16)
     ap.add_argument("--build-basecap", type=int, default=64)
     ap.add_argument("--build-maxdeg", type=int, default=384,
@@ -291,7 +294,7 @@ def main():
     if args.pmc_child:  # profiled child of measure_traffic(): the timed loop's launches and nothing else
         if not cached or not args.L:
             raise SystemExit("--pmc-child needs --graph-cache (an existing file) and --L")
-        idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2}[args.visited])
+        idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}[args.visited])
         if args.vis_entries:
             idx.set_option("vis_entries", args.vis_entries)
         for s_ in range(args.warmup + args.steps):
@@ -310,7 +313,7 @@ def main():
     log(f"[rank {rank}] brute-force ground truth for {B} x {mine} queries in {time.time() - t0:.1f}s "
         f"({'torch' if args.torch_gt else 'roar_exact_knn_device'})")
 
-    VIS = {"exact": 0, "lds": 1, "auto": 2}
+    VIS = {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}
     idx.set_option("visited_mode", VIS[args.visited])
     if args.vis_entries:
         idx.set_option("vis_entries", args.vis_entries)
@@ -426,6 +429,19 @@ def main():
             wall_ = t.item()
         return wall_, e0.elapsed_time(e1)  # events on the launch stream (torch's current stream is passed down)
 
+    run(chosen, 0, outs[0])
+    visited_desc = ("exact (u8 epoch tags in HBM)" if idx.info("last_visited_mode") == 0 else
+                    "lds-forgetful (on-chip tag table, a full set overwrites a victim)" if idx.info("last_visited_forgetful") else
+                    "lds-exact (on-chip tag table, full sets spill to u16 epoch tags in HBM)")
+    # the same launch with the on-chip table in its EXACT form (cmps = the reference's): what exact counting costs here
+    idx.set_option("visited_mode", 1)
+    exact_form_ms, exact_form_cmps = 1e9, 0.0
+    for _ in range(3):
+        o_ = run(chosen, 0)
+        torch.cuda.synchronize()
+        exact_form_ms = min(exact_form_ms, idx.info("last_kernel_ns") * 1e-6)
+        exact_form_cmps = o_["cmps"].double().mean().item()
+    idx.set_option("visited_mode", VIS[args.visited])
     wall_replay, gpu_replay = timed(lambda s_: 0)           # the same batch every step (rows of the last step still cached)
     wall_serial, gpu_ms = timed(lambda s_: s_ % B)          # distinct batches in rotation, one launch after the other:
     last_kernel_ms = idx.info("last_kernel_ns") * 1e-6      #   the kernel's own duration (roofline) comes from this loop
@@ -465,7 +481,7 @@ def main():
                    "parallelism": (f"index replicated on {world} GPU(s); one {args.nq}-query batch per step split by query, "
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),
-                   "visited": {0: "exact", 1: "lds"}[idx.info("last_visited_mode")],
+                   "visited": visited_desc,
                    "waves_per_query": idx.info("last_waves_per_query"), "register_pool": bool(idx.info("last_register_pool")),
                    "builder": args.builder, "index": index_desc, "graph_hash": f"{graph_hash:016x}",
                    "avg_degree": idx.info("nedges") / args.n, "adjacency_stride_words": idx.info("adj_stride"),
@@ -481,6 +497,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch, "queries_per_launch": mine,
                      "avg_cmps": ref_cmps, "avg_hops": ref_hops, "avg_scanned": ref_scan,
                      "kernel_cmps": lds_cmps, "grid": idx.info("last_grid"),
+                     "kernel_ms_with_exact_on_chip_visited_set": exact_form_ms, "kernel_cmps_with_exact_on_chip_visited_set": exact_form_cmps,
                      "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids,
                      # north_star asks for MFMA utilisation beside HBM GB/s: this kernel is GEMV shaped
                      # (0.5 flop/B) and issues no MFMA; the repo's MFMA kernel is the exact-kNN generator

@@ -44,7 +44,7 @@ enum {
  * ids / distances / hops are identical to the reference in every mode; cmps is the reference's in EXACT and LDS and can
  * only be >= it in LDS_FORGETFUL.  (If HBM cannot hold one spill list per resident workgroup -- 2 n bytes each -- an LDS
  * launch runs forgetful; info key "last_visited_forgetful" says so.) */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: chosen per launch from L_pq and the graph, csrc/roar_capi.cpp plan_search */, ROAR_VISITED_LDS_FORGETFUL = 3 };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the fastest form for the launch -- LDS_FORGETFUL up to L_pq ~ 500-1950 (by the graph's density and the hub form, csrc/roar_capi.cpp plan_search), EXACT beyond */, ROAR_VISITED_LDS_FORGETFUL = 3 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -345,8 +345,10 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value);
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
 
 /* Testing hook for the error paths: the n-th device allocation the library makes from now on fails as if HBM were
- * exhausted (n <= 0 disarms; ROAR_FAIL_AT=n in the environment arms it at load).  tests/test_gpu_parity.py walks n over
- * load / search / build scenarios and checks that every failure is reported and leaves no device memory behind. */
+ * exhausted (n <= 0 disarms; ROAR_FAIL_AT=n in the environment arms it at load).  Returns how many allocations were still
+ * to go on the previous arming (0: it was disarmed or has fired).  tests/test_gpu_parity.py walks n over load / search /
+ * clone scenarios and checks that every failure is either reported as ROAR_ERR_DEVICE or absorbed by a documented
+ * fallback, and leaves no device memory behind. */
 int roar_debug_fail_device_alloc_at(int64_t n);
 
 /* Known-answer surface for NeighborPriorityQueue (include/efanna2e/neighbor.h:138-223): replays a scripted sequence on

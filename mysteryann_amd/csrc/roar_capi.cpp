@@ -550,7 +550,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
                    : idx->visited_mode;
     // LDS: the exact form (ids that find their set full go to the spill list in HBM); LDS_FORGETFUL: a full set overwrites
     // a victim (cmps >= the reference's, nothing stored to HBM); the builder's searches and the two-hop walk forget
-    bool forget = mode == ROAR_VISITED_LDS_FORGETFUL || idx->building || bipartite;
+    // AUTO takes the forgetful form wherever it takes the table at all: it is the faster one at every L_pq on both benchmark
+    // graphs (T2I-10M, 10 000 queries, forgetful / exact: L_pq = 55 3.652 / 3.667 ms, 100 6.02 / 6.29, 200 11.04 / 12.00, 500
+    // 25.8 / 30.1, 1 000 54.1 / 61.6, 1 400 77.0 / 84.2, 2 000 117.8 / 125.2 ms; profiles/r03_visited_forms.txt) -- a one-word
+    // mark stored to HBM costs as much as 2-3.5 lines of a row gather (profiles/r03_probe_cost.txt), an id beyond the
+    // table's capacity is asked for again only one time in three, and a forgotten one costs its 7 row lines only then.
+    bool forget = mode == ROAR_VISITED_LDS_FORGETFUL || idx->building || bipartite ||
+                  (idx->visited_mode == ROAR_VISITED_AUTO && mode == ROAR_VISITED_LDS);
     if (mode == ROAR_VISITED_LDS_FORGETFUL) mode = ROAR_VISITED_LDS;
     // bipartite, AUTO: eight waves per query while the pool is short (work per query is far too uneven for one
     // wave each: T2I-10M, 10 000 queries, 14.0 / 20.0 / 32.8 / 44.9 / 68.2 ms at L_pq = 10 / 20 / 50 / 100 / 200 against
@@ -2400,8 +2406,8 @@ int roar_queue_trace(int device, uint32_t capacity, uint32_t n_ops, const uint8_
 }
 
 int roar_debug_fail_device_alloc_at(int64_t n) {
-    g_fail_alloc_in.store(n > 0 ? n : 0);
-    return ROAR_OK;
+    const int64_t left = g_fail_alloc_in.exchange(n > 0 ? n : 0);
+    return (int)std::min<int64_t>(std::max<int64_t>(left, 0), 0x7FFFFFFF);  // > 0: it was armed and has not fired
 }
 
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq) {

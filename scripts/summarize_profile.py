@@ -39,7 +39,29 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
 trace = search_rows(newest(os.path.join(src, "trace/*/*_kernel_trace.csv")))
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace]
 timed = durs[-8:]  # the rotating timed loop is the last thing the process launches
-# 3. PMC
+# 3. PMC (round 3: bench.py measures them itself, in its own two --pmc child passes: --traffic-from-bench)
+if "--traffic-from-bench" in sys.argv:
+    rf = bench["roofline"]
+    summary = {
+        "command": f"python3 bench.py --steps 8 --warmup 1 --in-flight 1 --no-cpu-baseline --no-host-path --no-traffic --L {Lchosen}",
+        "kernel": "roar_search_v2_kernel<VIS_LDS, IP, NCH=12, TAIL, W=1, register pool> (D=200)",
+        "timed_launch_durations_ns": timed,
+        "avg_launch_ms_rocprof": sum(timed) / len(timed) / 1e6,
+        "avg_launch_ms_bench_hip_events": rf["kernel_ms"],
+        "FETCH_SIZE_KB_raw_per_launch": rf.get("FETCH_SIZE_KB_raw_per_launch"),
+        "WRITE_SIZE_KB_raw_per_launch": rf.get("WRITE_SIZE_KB_raw_per_launch"),
+        "hbm_traffic_bytes_per_launch_corrected": rf.get("traffic"),
+        "l2_hit_share": rf.get("l2_hit_share"), "beyond_l2_bytes": rf.get("beyond_l2_bytes"),
+        "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+        "traffic_over_algorithmic": (rf["traffic"] / rf["algorithmic_bytes_per_launch"]) if rf.get("traffic") else None,
+        "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), measured by bench.py's own --pmc child passes",
+        "bench_line": bench,
+    }
+    json.dump(summary, open(os.path.join(out, f"{tag}_search_kernel_summary.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1))
+    sys.exit(0)
+
+
 def pmc(name):
     rows = search_rows(newest(os.path.join(src, f"{name}/*/*_counter_collection.csv")))
     return [float(r["Counter_Value"]) for r in rows][-8:], [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows][-8:]

@@ -1032,24 +1032,25 @@ def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib)
     scenario()  # warm: code objects, runtime pools
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    failures = 0
-    for nth in range(1, 200):
+    failures = absorbed = 0
+    for nth in range(1, 400):
         lib.roar_debug_fail_device_alloc_at(nth)
+        left = 0
         try:
             scenario()
-            completed = True
+            absorbed += 1  # e.g. no room for the spill lists: the launch runs the forgetful form instead
         except mi.RoarError as e:
-            completed = False
             failures += 1
             assert e.code == capi.ERR_DEVICE, (nth, e)
         finally:
-            lib.roar_debug_fail_device_alloc_at(0)
+            left = lib.roar_debug_fail_device_alloc_at(0)
         torch.cuda.synchronize()
         free = torch.cuda.mem_get_info()[0]
         assert abs(free - free0) <= (4 << 20), (nth, free0 - free)
-        if completed:
+        if left > 0:  # the scenario made fewer than nth allocations: every one of them has been failed once
+            absorbed -= 1
             break
-    assert failures >= 20, failures  # the scenario makes a few dozen device allocations
+    assert failures >= 20 and absorbed <= 6, (failures, absorbed)  # the scenario makes a few dozen device allocations
     scenario()  # and the library still works
 
 

@@ -56,6 +56,7 @@ int roar_rg_list_prune(const float *base, uint64_t ld, uint32_t dim, int ip, int
 int roar_rg_supply_prune(const float *base, uint64_t ld, uint32_t dim, int ip, const uint32_t *res_ids, const float *res_d,
                          uint32_t Lres, uint32_t count, uint32_t t0, const uint32_t *grows, uint32_t Sg, uint32_t M,
                          unsigned long long *keyscratch, uint32_t scratch_waves, uint32_t *out, uint32_t *cnt, void *stream);
+int roar_rg_check_lists(const uint32_t *lists, uint32_t K, uint32_t C, uint64_t count, uint32_t n, uint32_t *bad_dev, void *stream);
 int roar_rg_last_list(const uint32_t *lists, uint32_t K, uint32_t count, uint32_t sq0, uint32_t *last, void *stream);
 int roar_rg_set_rows(uint32_t *rows, uint32_t S, const uint32_t *lists, uint32_t K, uint32_t count, uint32_t sq0, uint32_t t0,
                      int by_pivot, const uint32_t *last, const uint32_t *out, const uint32_t *cnt, uint32_t M,
@@ -1467,6 +1468,19 @@ int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint
     RG_HIP(roar_dev_malloc((void **)&sums, idx->dim_pad * sizeof(float)));
     RG_HIP(roar_dev_malloc((void **)&scratch, 16));
 
+    // the lists come from the caller's device memory: every id the projection reads must name a base point
+    {
+        uint32_t bad = 0;
+        RG_HIP(hipMemset(scratch, 0, 16));
+        for (uint64_t a = 0; a < n_learn; a += batch_lists)
+            RG_TRY(roar_rg_check_lists(lists_dev + a * K, K, C, std::min<uint64_t>(batch_lists, n_learn - a), (uint32_t)n, scratch, nullptr));
+        RG_HIP(hipMemcpy(&bad, scratch, 4, hipMemcpyDeviceToHost));
+        if (bad) {
+            drop_graph();
+            cleanup();
+            return fail(ROAR_ERR_FORMAT, "learn base knn file error");  // (an id outside the base set)
+        }
+    }
     // CalculateProjectionep (:2004-2041)
     RG_TRY(roar_bk_entry_point(idx->base, idx->ld, idx->dim_pad, n, sums, (unsigned long long *)scratch, nullptr));
     unsigned long long best = 0;

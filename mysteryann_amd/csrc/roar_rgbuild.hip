@@ -654,6 +654,23 @@ int roar_rg_supply_prune(const float *base, uint64_t ld, uint32_t dim, int ip, c
     });
 }
 
+// lists[count][K]: the first C ids of every list must name base points (id < n; 0xFFFFFFFF = no entry) -- the device form of the
+// check roar_build_roargraph makes on the host ("learn base knn file error").  *bad is raised, never cleared.
+__global__ void rg_check_lists_kernel(const uint32_t *__restrict__ lists, uint32_t K, uint32_t C, u64 cells, uint32_t n, uint32_t *bad) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const uint32_t id = lists[(i / C) * K + (i % C)];
+    if (id >= n && id != 0xFFFFFFFFu) *bad = 1u;
+}
+
+extern "C" int roar_rg_check_lists(const uint32_t *lists, uint32_t K, uint32_t C, uint64_t count, uint32_t n, uint32_t *bad_dev, void *stream) {
+    const u64 cells = (u64)count * C;
+    if (cells == 0) return 0;
+    hipLaunchKernelGGL(rg_check_lists_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lists, K, C,
+                       cells, n, bad_dev);
+    return (int)hipGetLastError();
+}
+
 int roar_rg_last_list(const uint32_t *lists, uint32_t K, uint32_t count, uint32_t sq0, uint32_t *last, void *stream) {
     if (count == 0) return 0;
     hipLaunchKernelGGL(rg_last_list_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, lists, K, count, sq0,

@@ -151,7 +151,10 @@ class IndexBipartite:
     def BuildRoarGraphDevice(self, learn_knn, parameters):
         """BuildRoarGraph from learn->base lists that already live in HBM (int32 CUDA/HIP tensor [n_learn, K], e.g. the
         output of ExactKnnDevice): roar_build_roargraph_device."""
-        assert learn_knn.is_cuda and learn_knn.is_contiguous() and learn_knn.element_size() == 4
+        import torch
+
+        assert learn_knn.is_cuda and learn_knn.is_contiguous() and learn_knn.dtype in (torch.int32, torch.uint32), \
+            "learn->base lists must be an int32 / uint32 CUDA tensor [n_learn, K]"
         capi.check(self._lib.roar_build_roargraph_device(self._h, C.c_void_p(learn_knn.data_ptr()), learn_knn.shape[0],
                                                          learn_knn.shape[1], parameters.Get("M_sq", int),
                                                          parameters.Get("M_pjbp", int), parameters.Get("L_pjpq", int)))

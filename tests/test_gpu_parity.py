@@ -992,6 +992,34 @@ def test_device_builder_matches_the_survey_probe_of_the_compiled_reference(golde
     idx.close()
 
 
+def test_device_builder_refuses_lists_that_name_no_base_point(built_lib):
+    """roar_build_roargraph_device reads the learn->base lists from the caller's HBM: an id outside the base set must be
+    refused like the host form refuses it ("learn base knn file error"), not read or written out of bounds; a float tensor
+    is refused by the Python mirror."""
+    import torch
+
+    from mysteryann_amd import capi
+    from mysteryann_amd import index as mi, synth
+
+    n = 3000
+    base, q, learn = synth.t2i_numpy(n, 8, 200, n_learn=500)
+    idx = mi.IndexBipartite(200, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    lists, _ = idx.ExactKnnDevice(torch.from_numpy(learn).cuda(), 100, want_dists=False)
+    p = mi.Parameters()
+    p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 100)
+    bad = lists.clone()
+    bad[123, 7] = n + 5
+    with pytest.raises(mi.RoarError) as e:
+        idx.BuildRoarGraphDevice(bad, p)
+    assert e.value.code == capi.ERR_FORMAT and "learn base knn file error" in str(e.value)
+    with pytest.raises(AssertionError):
+        idx.BuildRoarGraphDevice(lists.float(), p)
+    idx.BuildRoarGraphDevice(lists, p)  # the untouched lists still build
+    assert idx.info("nedges") > 0
+    idx.close()
+
+
 def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib):
     """Fault injection (roar_debug_fail_device_alloc_at: the n-th device allocation of the library fails as if HBM were
     exhausted), n = 1, 2, ... over a scenario that loads, searches in every visited form (spill lists, tag pools, hub rows

@@ -384,6 +384,8 @@ def main():
         alg_bytes.append((4 * dpad * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum()
                           + 8 * ex["hops"].double().sum() + (4 * dpad + 8 * args.k) * mine).item())
         same_ids = same_ids and bool((ex["ids"] == o["ids"]).all().item() and (ex["dists"] == o["dists"]).all().item())
+        if b == 0:
+            ex0_cmps = ex["cmps"].clone()
         ref_cmps += ex["cmps"].double().mean().item() / B
         ref_hops += ex["hops"].double().mean().item() / B
         ref_scan += ex["scanned"].double().mean().item() / B
@@ -441,6 +443,7 @@ def main():
         torch.cuda.synchronize()
         exact_form_ms = min(exact_form_ms, idx.info("last_kernel_ns") * 1e-6)
         exact_form_cmps = o_["cmps"].double().mean().item()
+        exact_form_equal = bool((o_["cmps"] == ex0_cmps).all().item())
     idx.set_option("visited_mode", VIS[args.visited])
     wall_replay, gpu_replay = timed(lambda s_: 0)           # the same batch every step (rows of the last step still cached)
     wall_serial, gpu_ms = timed(lambda s_: s_ % B)          # distinct batches in rotation, one launch after the other:
@@ -498,6 +501,7 @@ def main():
                      "avg_cmps": ref_cmps, "avg_hops": ref_hops, "avg_scanned": ref_scan,
                      "kernel_cmps": lds_cmps, "grid": idx.info("last_grid"),
                      "kernel_ms_with_exact_on_chip_visited_set": exact_form_ms, "kernel_cmps_with_exact_on_chip_visited_set": exact_form_cmps,
+                     "exact_on_chip_visited_set_cmps_equal_reference_for_every_query_of_batch_0": exact_form_equal,
                      "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids,
                      # north_star asks for MFMA utilisation beside HBM GB/s: this kernel is GEMV shaped
                      # (0.5 flop/B) and issues no MFMA; the repo's MFMA kernel is the exact-kNN generator

@@ -714,12 +714,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
 // Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of
 // a scoring pass for an occupancy the LDS footprint does not allow anyway).
-// (128-d rows: a scoring pass holds 2 x 8 float4 per lane, not 2 x 13 -- the kernel fits four waves per SIMD, and rows of
-// 512 bytes leave so little in flight per wave that the launch lives on resident waves)
-constexpr int waves_per_simd(int nch) { return nch == 8 ? 4 : 3; }
-
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(waves_per_simd(NCH), waves_per_simd(NCH))))
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
     search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED>(p);
 }

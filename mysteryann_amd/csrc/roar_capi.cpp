@@ -228,6 +228,7 @@ struct roar_index {
     int64_t last_combined = 0;
     // last launch
     int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
+    std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel form, LDS bytes) -> resident workgroups per CU
 };
 
 namespace {
@@ -649,8 +650,18 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product shape only");
     int occ = 0;
     auto occupancy = [&](int *out) -> int {
+        // (asked once per kernel form and LDS size: a stream of launches of one shape must not pay a runtime query each)
+        const uint64_t key = ((uint64_t)p.lds_bytes << 32) | ((uint64_t)(sel.form & 7) << 28) | ((uint64_t)(sel.waves & 7) << 24) |
+                             ((uint64_t)(sel.visited_mode & 3) << 20) | ((uint64_t)(sel.regpool & 1) << 19) | ((uint64_t)(sel.prof & 1) << 18) |
+                             ((uint64_t)(sel.hub & 1) << 17) | ((uint64_t)(sel.metric_ip & 1) << 16) | (uint64_t)(idx->dim_pad & 0xFFFF);
+        for (const auto &e : idx->occ_cache)
+            if (e.first == key) {
+                *out = e.second;
+                return ROAR_OK;
+            }
         int rc = roar_search_occupancy(&sel, idx->dim_pad, p.lds_bytes, out);
         if (rc != 0) return fail(ROAR_ERR_DEVICE, "occupancy query failed: %s", hipGetErrorString((hipError_t)rc));
+        if (idx->occ_cache.size() < 64) idx->occ_cache.emplace_back(key, *out);
         return ROAR_OK;
     };
     bool picked = false;

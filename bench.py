@@ -69,6 +69,41 @@ def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048,
     return out
 
 
+def build_reference_graph(torch, mi, idx, learn, n_exact, stage2_L, say=log):
+    """The benchmark's index: the reference's BuildRoarGraph (canonical parameters M_sq = 100, M_pjbp = 35, L_pjpq = 500,
+    run_roargraph_test.sh:9) on learn->base lists of ALL of `learn` (the reference's own T2I-10M run has as many training
+    queries as base points).  Exact lists (f32 MFMA brute force) cost 50 s per million training queries, so only the first
+    n_exact of them get exact lists; those make a first graph, the lists of the others are SEARCHED on it (k = 100,
+    L_pq = stage2_L: seconds for 8 M queries), and the final graph is built from all lists by the same BuildRoarGraph.
+    T2I-10M, 2 M exact + 8 M searched at L_pq = 200 / 400 / 600 / 1 000: recall@10 at L_pq = 50 0.8994 / 0.9004 / 0.9011 /
+    0.9007 (10 M exact lists, 501 s: 0.9005; 2 M exact lists alone: 0.8954).  -> description"""
+    import time as _t
+
+    n_learn = learn.shape[0]
+    n_exact = min(n_exact, n_learn)
+    t0 = _t.time()
+    lists, _ = idx.ExactKnnDevice(learn[:n_exact], 100, want_dists=False)
+    torch.cuda.synchronize()
+    say(f"exact learn->base kNN ({n_exact} x 100, MFMA generator) in {_t.time() - t0:.1f}s")
+    p = mi.Parameters()
+    p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 500)
+    idx.BuildRoarGraphDevice(lists, p)
+    if n_learn <= n_exact:
+        return f"reference shape: exact lists of {n_exact} training queries, M_sq=100 M_pjbp=35 L_pjpq=500"
+    t1 = _t.time()
+    all_lists = torch.empty((n_learn, 100), dtype=torch.int32, device=learn.device)
+    all_lists[:n_exact] = lists
+    del lists
+    for a in range(n_exact, n_learn, 50_000):
+        b_ = min(n_learn, a + 50_000)
+        all_lists[a:b_] = idx.SearchRoarGraphBatchDevice(learn[a:b_].contiguous(), 100, stage2_L)["ids"]
+    torch.cuda.synchronize()
+    say(f"searched lists of {n_learn - n_exact} more training queries (k=100, L_pq={stage2_L}) in {_t.time() - t1:.1f}s")
+    idx.BuildRoarGraphDevice(all_lists, p)
+    return (f"reference shape, two stages: exact lists of {n_exact} training queries -> graph -> lists of {n_learn - n_exact} more "
+            f"searched on it (k=100, L_pq={stage2_L}) -> BuildRoarGraph on all {n_learn} lists, M_sq=100 M_pjbp=35 L_pjpq=500")
+
+
 def recall_at_k(torch, ids, gt, k):
     hit = (gt[:, :k, None] == ids[:, None, :k].to(torch.int64)).any(dim=2).sum().item()
     return hit / float(k * ids.shape[0])
@@ -159,6 +194,13 @@ def parse_args(argv=None):
     ap.add_argument("--ref-learn", type=int, default=0,
                     help="--builder reference: training queries whose exact top-100 lists are computed (0 = n / 5; T2I-10M: "
                          "1 M / 2 M / 4 M lists -> recall 0.903 / 0.908 / 0.911 at L_pq 55, 50 / 100 / 200 s of f32 MFMA)")
+    ap.add_argument("--ref-learn2", type=int, default=-1,
+                    help="--builder reference, second stage: this many training queries in all (-1 = default: as many as base points, the "
+                         "reference's own T2I-10M setting, for the t2i workload; 0 for the others = no second stage).  The first --ref-learn of them get exact lists (MFMA brute force) and make a first "
+                         "graph; the lists of the others are SEARCHED on that graph (k = 100, L_pq = --ref-learn2-L: 10 M searches take "
+                         "seconds where 10 M exact lists take 500 s), and the final graph is built from all lists by the same "
+                         "BuildRoarGraph with the same canonical parameters")
+    ap.add_argument("--ref-learn2-L", type=int, default=600)
     ap.add_argument("--graph-cache", default="",
                     help="index file: loaded if it exists (LoadProjectionGraph), else written after the build -- lets the "
                          "profiling passes of one box session (scripts/profile_r2.sh) skip the four-minute build; the graph "
@@ -230,8 +272,11 @@ def main():
     B = max(1, args.batches)
     t0 = time.time()
     n_learn = args.learn if args.learn >= 0 else args.n
+    n_exact = 0
     if args.builder == "reference":
-        n_learn = args.ref_learn or args.n // 5
+        n_exact = args.ref_learn or args.n // 5
+        stage2 = args.ref_learn2 if args.ref_learn2 >= 0 else (args.n if args.workload == "t2i" else 0)
+        n_learn = max(n_exact, stage2)
     gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch}[args.workload]
     # B batches of nq queries in one draw; strong scaling: every rank draws the SAME block and takes its rows of each batch
     base, qall, learn = gen(args.n, args.nq * B, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
@@ -254,15 +299,7 @@ def main():
         idx.LoadProjectionGraph(args.graph_cache)
         index_desc = f"loaded from {os.path.basename(args.graph_cache)} (written by an earlier run of this command on this box)"
     elif args.builder == "reference":
-        lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
-        torch.cuda.synchronize()
-        knn_s = time.time() - t0
-        log(f"[rank {rank}] exact learn->base kNN ({n_learn} x 100, MFMA generator) in {knn_s:.1f}s")
-        p = mi.Parameters()
-        p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 500)
-        idx.BuildRoarGraphDevice(lists, p)
-        index_desc = f"reference shape: exact lists of {n_learn} training queries, M_sq=100 M_pjbp=35 L_pjpq=500"
-        del lists
+        index_desc = build_reference_graph(torch, mi, idx, learn, n_exact, args.ref_learn2_L, lambda m_: log(f"[rank {rank}] {m_}"))
     else:
         if args.exact_knn and n_learn:
             ne = min(args.exact_knn, n_learn)
@@ -584,7 +621,7 @@ def measure_traffic(args, idx, L, nq_launch):
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
              "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
              "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
-             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1"]
+             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0"]
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     try:

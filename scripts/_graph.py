@@ -6,9 +6,11 @@ import torch
 from mysteryann_amd import index as mi, synth
 
 
-def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="/tmp/r2_graph.index", say=print):
+def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="/tmp/r3_graph2.index", say=print, stage2=-1, stage2_L=600):
+    """bench.py's default index (two-stage training lists, bench.build_reference_graph) unless told otherwise."""
     d = 200
-    n_learn = (ref_learn or n // 5) if builder == "reference" else n
+    n_exact = ref_learn or n // 5
+    n_learn = max(n_exact, n if stage2 < 0 else stage2) if builder == "reference" else n
     have = bool(cache) and os.path.exists(cache)
     base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=0 if have else n_learn)
     idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
@@ -17,10 +19,8 @@ def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="
     if have:
         idx.LoadProjectionGraph(cache)
     elif builder == "reference":
-        lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
-        p = mi.Parameters(); p.Set("M_sq", 100); p.Set("M_pjbp", 35); p.Set("L_pjpq", 500)
-        idx.BuildRoarGraphDevice(lists, p)
-        del lists
+        import bench
+        bench.build_reference_graph(torch, mi, idx, learn, n_exact, stage2_L, lambda m: say("# " + m))
     else:
         idx.BuildBootstrapGraph(learn=learn, max_degree=384, row_keep=128)
     torch.cuda.synchronize()

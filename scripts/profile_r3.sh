@@ -9,11 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3/profile
 mkdir -p $O
 cd $R
-python3 bench.py --graph-cache /tmp/r3_graph.index > $O/bench.json 2> $O/bench.err
+python3 bench.py --graph-cache /tmp/r3_graph2.index > $O/bench.json 2> $O/bench.err
 tail -3 $O/bench.err; cat $O/bench.json
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--graph-cache /tmp/r3_graph.index --steps 8 --warmup 1 --in-flight 1 --no-cpu-baseline --no-host-path --no-traffic --L $(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['L_pq'])")"
+ARGS="--graph-cache /tmp/r3_graph2.index --steps 8 --warmup 1 --in-flight 1 --no-cpu-baseline --no-host-path --no-traffic --L $(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['L_pq'])")"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $ARGS > $O/trace.json 2> $O/trace.err
 echo "trace rc=$?"; tail -2 $O/trace.err
 cd $R

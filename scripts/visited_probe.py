@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from _graph import t2i_index
 
-idx, base, queries = t2i_index(10_000_000, 10_000, "reference", 0, "/tmp/r3_graph.index")
+idx, base, queries = t2i_index(10_000_000, 10_000, "reference", 0, "/tmp/r3_graph2.index")
 q = queries.contiguous()
 K = 10
 Ls = [int(x) for x in os.environ.get("LS", "55,100,200,300,500,700,1000,1400,2000").split(",")]

@@ -121,8 +121,11 @@ def free_port():
 def launcher_command(argv, gpus, port):
     """Command line that runs this script as `gpus` ranks of one node, one per GPU, over RCCL -- what the driver types
     for N > 1.  argv = this process's own arguments (sys.argv[1:]), passed through unchanged."""
+    # (the launcher's parser would read a bare `--n` behind the script as an abbreviation of its own --nnodes / --nproc-per-node /
+    # ...: spell it out)
+    argv = ["--base-points" if a == "--n" else ("--base-points=" + a[4:] if a.startswith("--n=") else a) for a in argv]
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
 
 
 def self_launch(args, argv):

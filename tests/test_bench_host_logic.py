@@ -58,6 +58,8 @@ def test_plain_multi_gpu_command_starts_the_ranks_as_a_child(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
     script = cmd.index(os.path.abspath(bench.__file__))
     assert cmd[script + 1:] == argv  # the script's own arguments pass through unchanged, after the script
+    # `--n` would be taken by the launcher's own parser as an abbreviation of --nnodes / --nproc-per-node: it is spelled out
+    assert bench.launcher_command(["--gpus", "2", "--n", "1000"], 2, 1)[-4:] == ["--gpus", "2", "--base-points", "1000"]
     calls = []
     monkeypatch.setattr(subprocess, "call", lambda c, env=None: calls.append((c, env)) or 17)
     monkeypatch.delenv("RANK", raising=False)

@@ -500,7 +500,7 @@ def main():
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
     result = {
-        "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD" if args.workload == "t2i"
+        "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD" if (args.workload, args.n) == ("t2i", 10_000_000)
         else f"QPS @ recall@10={args.target_recall}, {args.workload} shape",
         "value": qps,
         "unit": "queries/s",

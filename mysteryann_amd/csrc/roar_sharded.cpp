@@ -43,6 +43,19 @@ int sfail(int code, const char *fmt, ...) {
     return code;
 }
 
+struct DeviceRestore {  // the caller's current device is put back on every exit
+    int prev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+    }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 struct Rank {
     int device = 0;
     std::vector<uint32_t> shards;  // shard numbers placed on this device, ascending
@@ -150,8 +163,10 @@ int roar_sharded_create(roar_sharded **out, uint32_t dim, int metric, const int 
     if (!out) return sfail(ROAR_ERR_ARG, "null output pointer");
     *out = nullptr;
     if (!devices || n_shards == 0 || n_shards > 32) return sfail(ROAR_ERR_ARG, "between 1 and 32 shards");
+    DeviceRestore keep_device_;
     roar_sharded *sh = new (std::nothrow) roar_sharded();
     if (!sh) return sfail(ROAR_ERR_DEVICE, "out of host memory");
+    try {
     sh->dim = dim;
     sh->dim_pad = (dim + 7) / 8 * 8;
     sh->metric = metric;
@@ -193,12 +208,17 @@ int roar_sharded_create(roar_sharded **out, uint32_t dim, int metric, const int 
             return sfail(ROAR_ERR_DEVICE, "stream / events on device %d: %s", r.device, hipGetErrorString(e));
         }
     }
+    } catch (...) {  // (std::bad_alloc from the bookkeeping vectors: nothing may cross the C ABI)
+        roar_sharded_destroy(sh);
+        return sfail(ROAR_ERR_DEVICE, "out of host memory");
+    }
     *out = sh;
     return ROAR_OK;
 }
 
 void roar_sharded_destroy(roar_sharded *sh) {
     if (!sh) return;
+    DeviceRestore keep_device_;
     for (Rank &r : sh->ranks) {
         (void)hipSetDevice(r.device);
         if (r.stream) (void)hipStreamSynchronize(r.stream);
@@ -249,12 +269,7 @@ int roar_search_batch_sharded(roar_sharded *sh, const float *queries, uint64_t n
     if (k == 0 || k > L_pq) return sfail(ROAR_ERR_ARG, "L_pq must greater or equal than k");
     if (nq * (uint64_t)k >= (1ull << 31)) return sfail(ROAR_ERR_ARG, "too many results in one batch");
     std::lock_guard<std::mutex> guard(sh->mu);
-    int saved_device = 0;
-    (void)hipGetDevice(&saved_device);
-    struct Restore {
-        int d;
-        ~Restore() { (void)hipSetDevice(d); }
-    } restore{saved_device};
+    DeviceRestore keep_device_;
     const uint32_t S = (uint32_t)sh->shard.size(), R = (uint32_t)sh->ranks.size();
     // global id of every shard's row 0: as set, else the running sum of the shard sizes
     {
@@ -344,8 +359,15 @@ int roar_search_batch_sharded(roar_sharded *sh, const float *queries, uint64_t n
             roar_set_last_error(msg[ri].c_str());
             return rc[ri];
         }
+    auto drain = [&]() {  // after a failure: nothing of this call may still be running when the caller gets its buffers back
+        for (Rank &r : sh->ranks) {
+            (void)hipSetDevice(r.device);
+            (void)hipStreamSynchronize(r.stream);
+        }
+    };
     // phase 2: the exchange -- every rank's [local shard][nq][k] block to every rank (ids, then distances) -- and the merge
     const size_t blk = (size_t)sh->max_local * res;
+    auto phase2 = [&]() -> int {
     S_NCCL(ncclGroupStart());
     for (Rank &r : sh->ranks) {
         ncclResult_t a = ncclAllGather(r.send_ids, r.recv_ids, blk, ncclUint32, r.comm, r.stream);
@@ -387,6 +409,14 @@ int roar_search_batch_sharded(roar_sharded *sh, const float *queries, uint64_t n
     }
     sh->last_search_ns = search_ns;
     sh->last_exchange_ns = exch_ns;
+    return ROAR_OK;
+    };
+    if ((e = phase2())) {
+        const std::string keep = roar_last_error();
+        drain();
+        roar_set_last_error(keep.c_str());
+        return e;
+    }
     memcpy(ids, sh->res_pin, res * 4);
     memcpy(dists, sh->res_pin + res, res * 4);
     if (cmps || hops)

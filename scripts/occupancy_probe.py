@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from _graph import t2i_index
-idx, base, queries = t2i_index(10_000_000, 10000, "reference", 0, "/tmp/r2_graph.index")
-for L in (55, 100, 200):
+idx, base, queries = t2i_index(10_000_000, 10000, "reference", 0, "/tmp/r3_graph2.index")
+for L in (50, 100, 200):
     for nq in (10000, 2500):
         q = queries[:nq].contiguous()
         for w in (4, 5, 6, 7, 8):

@@ -9,8 +9,9 @@
 //   * while the rows of a hop are being scored, the adjacency row of the LIKELY next expansion (the closest
 //     unexpanded pool entry as it stands before the hop's merges) is already in flight; it is used if the merges
 //     leave that entry in front, dropped otherwise (results cannot depend on it);
-//   * the visited filter runs over the whole row at once (LDS mode: three compare-and-swaps per lane in flight;
-//     EXACT mode: the tag loads of all three chunks in flight; long pools: the highest-in-degree nodes have their
+//   * the visited filter runs over the whole row at once (LDS modes: three compare-and-swaps per lane in flight, a full
+//     set either spills to the workgroup's epoch list in HBM -- exact -- or overwrites a victim -- forgetful, see
+//     visited_ldsn; EXACT mode: the tag loads of all three chunks in flight; long pools: the highest-in-degree nodes have their
 //     visited bits in an exact on-chip bitmap, named by slot in a hub-annotated copy of the adjacency, and only the
 //     other neighbours go to the tag table / the HBM tags), the survivors of the whole hop are packed, scored
 //     R x 16 rows per pass -- every load of a pass, the 8-float tail of a D = 200 row included, issued before the

@@ -5,7 +5,7 @@
 //   reference (CPU)                                   here (per wave)
 //   ------------------------------------------------  ---------------------------------------------
 //   NeighborPriorityQueue  neighbor.h:138-223         sorted u64 keys  (ord(dist)<<32 | id<<1 | expanded)
-//   VisitedList            visited_list_pool.h:8-29   LDS 4-way u16 tag table (mode LDS) or u8 epoch tags in HBM (mode EXACT)
+//   VisitedList            visited_list_pool.h:8-29   LDS 4-way u16 tag table (+ u16 epoch spill list in HBM: exact; or forgetful), or u8 epoch tags in HBM (mode EXACT)
 //   distance_->compare     distance.h:39-89,179-223   4 lanes per row, 64-B pieces, fmaf chains, quad-DPP reduction tree
 //
 // Distances are bit-identical to the reference's AVX-512 code as gcc builds it (-Ofast contracts

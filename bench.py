@@ -222,6 +222,7 @@ def parse_args(argv=None):
                     help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of measure_traffic()
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-screen", action="store_true", help="switch the half-precision screening pass off (option screen = 1)")
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
     ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
     ap.add_argument("--sweep", action="store_true", help="print the whole L_pq curve (CSV columns of the reference)")
@@ -335,6 +336,7 @@ def main():
         if not cached or not args.L:
             raise SystemExit("--pmc-child needs --graph-cache (an existing file) and --L")
         idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}[args.visited])
+        idx.set_option("screen", 1 if args.no_screen else 0)
         if args.vis_entries:
             idx.set_option("vis_entries", args.vis_entries)
         for s_ in range(args.warmup + args.steps):
@@ -354,6 +356,7 @@ def main():
         f"({'torch' if args.torch_gt else 'roar_exact_knn_device'})")
 
     VIS = {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}
+    idx.set_option("screen", 1 if args.no_screen else 0)
     idx.set_option("visited_mode", VIS[args.visited])
     if args.vis_entries:
         idx.set_option("vis_entries", args.vis_entries)
@@ -528,6 +531,7 @@ def main():
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),
                    "visited": visited_desc,
+                   "half_precision_screen": bool(idx.info("last_screen")),
                    "waves_per_query": idx.info("last_waves_per_query"), "register_pool": bool(idx.info("last_register_pool")),
                    "builder": args.builder, "index": index_desc, "graph_hash": f"{graph_hash:016x}",
                    "avg_degree": idx.info("nedges") / args.n, "adjacency_stride_words": idx.info("adj_stride"),
@@ -627,7 +631,7 @@ def measure_traffic(args, idx, L, nq_launch):
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
              "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
              "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
-             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0"]
+             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0"] + (["--no-screen"] if args.no_screen else [])
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     try:

@@ -322,6 +322,11 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row
  *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on dense graphs (same measure);
  *                    results do not depend on it
+ *   "screen"         0 auto | 1 off: 200-d inner-product / cosine indexes keep a half-precision copy of the base rows (416
+ *                    bytes per row) and a hop scores its unvisited neighbours on it first; a neighbour whose exact key is
+ *                    CERTAINLY above the pool's reject threshold (rigorous bound on the half-precision error) is dropped
+ *                    there, the others are scored on the f32 rows as before -- ids, distances, hops and cmps do not depend on
+ *                    it (csrc/roar_search_v2.h, screen_pass)
  *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
@@ -331,7 +336,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
  *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
  *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
- *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_kernel_ns"
+ *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "last_visited_forgetful", "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */
 int roar_set_option(roar_index *idx, const char *key, int64_t value);

@@ -132,6 +132,11 @@ struct roar_index {
     // base rows in HBM
     float *base = nullptr;
     bool base_owned = false;
+    // half-precision screening copy of a 200-d inner-product base set (RoarSearchParams::screen), n x 416 bytes, made on first use
+    unsigned char *screen = nullptr;
+    uint64_t screen_n = 0;
+    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it), 1 off
+    int last_screen = 0;
     uint64_t n = 0;
     uint32_t ld = 0;
     // graph in HBM (fixed-stride rows) + host CSR copy for save / get
@@ -279,6 +284,9 @@ void free_bipartite(roar_index *idx) {
 }
 
 void free_base(roar_index *idx) {
+    if (idx->screen) (void)hipFree(idx->screen);
+    idx->screen = nullptr;
+    idx->screen_n = 0;
     if (idx->base && idx->base_owned) (void)hipFree(idx->base);
     idx->base = nullptr;
     idx->base_owned = false;
@@ -479,6 +487,29 @@ int ensure_hub_rows(roar_index *idx) {
     return ROAR_OK;
 }
 
+// The screening copy (roar_search_v2.h, screen_pass): + n x 416 bytes of HBM, one conversion pass.  Failure to make it is not an
+// error: the launch then scores every neighbour on the f32 rows, as without it.
+void ensure_screen(roar_index *idx) {
+    if (idx->screen && idx->screen_n == idx->n) return;
+    if (idx->screen) (void)hipFree(idx->screen);
+    idx->screen = nullptr;
+    idx->screen_n = 0;
+    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * 416 + 256) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->screen = nullptr;
+        return;
+    }
+    int rc = roar_launch_make_screen(idx->base, idx->ld, idx->n, idx->screen, nullptr);
+    hipError_t e = rc == 0 ? hipDeviceSynchronize() : (hipError_t)rc;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(idx->screen);
+        idx->screen = nullptr;
+        return;
+    }
+    idx->screen_n = idx->n;
+}
+
 struct LaunchPlan {
     RoarSearchParams p;
     RoarKernelSel sel;
@@ -506,6 +537,12 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.base = idx->base;
     p.ld = idx->ld;
     p.dim = idx->dim_pad;
+    idx->last_screen = 0;
+    if (!bipartite && idx->ip && idx->dim_pad == 200 && idx->screen_mode == 0) {
+        ensure_screen(idx);
+        p.screen = idx->screen;
+        idx->last_screen = idx->screen ? 1 : 0;
+    }
     p.adj = idx->adj;
     p.adj_stride = idx->adj_stride;
     p.n = (uint32_t)idx->n;
@@ -1840,6 +1877,7 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
     dst->combine = src->combine;
     dst->hub_mode = src->hub_mode;
     dst->profile = src->profile;
+    dst->screen_mode = src->screen_mode;
     if ((e = alloc_base(dst, src->n))) return bail(e);
     // rows are re-strided to the padded dimension if the source adopted a wider block
     hipError_t he = hipSuccess;
@@ -2470,6 +2508,9 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "hub_mode") {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
         idx->hub_mode = (int)value;
+    } else if (k == "screen") {
+        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "screen must be 0 (auto) or 1 (off)");
+        idx->screen_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");
         idx->pool_form = (int)value;
@@ -2510,6 +2551,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
                  : idx->last_sel.form == ROAR_FORM_SEARCH ? idx->last_sel.waves : 1;
     else if (k == "last_register_pool") *value = idx->last_sel.regpool;
     else if (k == "last_hub_bitmap") *value = idx->last_sel.hub;
+    else if (k == "last_screen") *value = idx->last_screen;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

@@ -281,6 +281,87 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
     }
 }
 
+// ---- half-precision screening in front of the exact scoring (200-d inner-product shape) -----------------------------------
+// What a hop costs the memory system is counted in 128-byte line requests, and of the ~49 rows a hop scores
+// only ~6 have a key under the pool's reject threshold.  The index therefore keeps a second, half-precision copy of the base
+// rows -- 25 chunks of 8 halfs + one chunk whose first word is an upper bound of the row's Euclidean norm, 416 bytes = four
+// lines instead of seven -- and a hop first scores its unvisited neighbours on that copy.  For the exact distance d of a row
+// and its screened value d~ (f32 accumulation of q_i * half(x_i)):
+//     |d - d~| <= sum |q_i| |x_i - half(x_i)| + (rounding of 200 fused multiply-adds) <= |q| (EPS |x| + TINY),
+// EPS = 2^-11 (round-to-nearest half, normal range) + 2^-16 (gamma_200 of the f32 accumulation, generously), TINY covers halfs
+// in the subnormal range; a row with a component outside the half range carries the norm +inf.  A neighbour is dropped here
+// only if d~ - |q| (EPS |x| + TINY) > the threshold's distance, i.e. only if its exact key is certainly above the threshold
+// -- which the merge would have rejected (neighbor.h:151-153).  Everything else goes on to the exact pass, whose distances,
+// keys and merges are the ones of the reference, bit for bit.  cmps counts the neighbours BEFORE the screen, as the reference
+// counts its distance evaluations.  (The threshold is read before the hop's merges: it can only be looser than the reference's.)
+constexpr uint32_t SCREEN_STRIDE = 416;  // bytes per screening row: 26 chunks of 16 bytes
+#define ROAR_SCREEN_EPS 5.04e-4f          // 2^-11 + 2^-16, rounded up
+#define ROAR_SCREEN_TINY 4.3e-7f          // sqrt(200) * 2^-25, rounded up
+
+template <int RR>
+__device__ __forceinline__ void screen_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
+                                            float thr_d, float qnorm, uint32_t &w, int t, int g) {
+    uint32_t id[RR];
+    uint4 x[RR][7];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint32_t c = p0 + 16 * r + g;
+        id[r] = cid[c < m ? c : m - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * SCREEN_STRIDE);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x[r][j] = row[t + 4 * j];  // chunks t, t + 4, ..., t + 20: data for every lane
+        x[r][6] = row[(t & 1) ? 25 : 24];                      // lanes 0 / 2: chunk 24 (data, used by lane 0); lanes 1 / 3: the norm chunk
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
+    u64 bm[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int c = (j == 6) ? 24 : t + 4 * j;
+            const float4 qa = *reinterpret_cast<const float4 *>(lq + 8 * c), qb = *reinterpret_cast<const float4 *>(lq + 8 * c + 4);
+            // (chunk 24 belongs to lane 0; the other lanes hold something else in that register and add zeros)
+            const uint4 v = (j == 6 && t != 0) ? make_uint4(0, 0, 0, 0) : x[r][j];
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))), qa.x, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.x >> 16))), qa.y, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))), qa.z, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.y >> 16))), qa.w, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.z & 0xFFFFu))), qb.x, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.z >> 16))), qb.y, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.w & 0xFFFFu))), qb.z, acc);
+            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.w >> 16))), qb.w, acc);
+        }
+        float xn = __uint_as_float(x[r][6].x);  // (meaningful in lanes 1 and 3)
+        acc += quad_xor1(acc);
+        acc += quad_xor2(acc);                  // the four lanes' partial sums, in every lane of the group
+        xn = quad_xor1(xn);                     // lane 0 takes lane 1's word
+        const float lower = -acc - qnorm * __builtin_fmaf(ROAR_SCREEN_EPS, xn, ROAR_SCREEN_TINY);  // exact distance >= lower
+        const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
+        bm[r] = __ballot(keep);
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
+        w += (uint32_t)__popcll(bm[r]);
+    }
+    wave_sync();
+}
+
+// cid[0..m) -> the ids that may still have a key under the threshold, compacted in place (order kept); returns how many
+__device__ __forceinline__ uint32_t screen_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
+                                                float qnorm, int lane) {
+    const int t = lane & 3, g = lane >> 2;
+    uint32_t w = 0, p0 = 0;
+    for (; p0 + 16 < m; p0 += 32) screen_pass<2>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
+    for (; p0 < m; p0 += 16) screen_pass<1>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
+    return w;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue, which would
 // make wave 0 sit out the round trip of its speculative adjacency fetch before the other waves may start scoring;
 // everything the waves of a query hand each other (candidate ids, keys, control words) lives in LDS.
@@ -392,6 +473,16 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         }
         block_sync();
 
+        float qnorm = 0.f;  // |q|, rounded up (screen_pass)
+        if constexpr (IP && NCH == 12 && TAIL) {
+            if (wid == 0) {
+                float s2 = 0.f;
+                for (uint32_t i = lane; i < p.dim; i += 64) s2 = __builtin_fmaf(lq[i], lq[i], s2);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+                qnorm = __builtin_sqrtf(s2) * 1.0001f;
+            }
+        }
         // state of the sequential part (wave 0).  Pool: `pk` (register form, L_pq <= 64) or pool[] in LDS with the
         // cursor `cur` = index of the closest unexpanded entry.
         u64 pk = ~0ull;
@@ -573,6 +664,21 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         a1 = nrow[64 + lane];
                         a2 = nrow[128 + lane];
                         if (HUB) a3 = nrow[192 + lane];
+                    }
+                    if constexpr (IP && NCH == 12 && TAIL) {  // half-precision screen (see screen_pass), once the pool is full
+                        if (psize == L && m > 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                            const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+                            const unsigned char *scr = *const_cast<const unsigned char *const volatile *>(&ka->screen);
+#else
+                            const unsigned char *scr = nullptr;
+#endif
+                            if (scr) {
+                                wave_sync();
+                                const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
+                                m = screen_rows(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), qnorm, lane);
+                            }
+                        }
                     }
                     if (PROF) {
                         c1 = (long long)__builtin_readcyclecounter();

@@ -15,6 +15,7 @@
 // (distance, id) order, hence every expansion and every returned id, identical to the CPU path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #include "roar_device.h"

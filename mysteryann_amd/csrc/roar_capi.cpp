@@ -583,7 +583,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (sparse graph, L_pq 1 500 ... 1 900: a 4 096-tag table with six workgroups per CU re-scores 50 % more rows than the
     // reference and still beats the HBM tags, 82.1 / 87.6 / 93.1 / 98.5 ms against 85.1 / 91.5 / 96.1 / 101.0 ms at L_pq = 1 500 /
     // 1 600 / 1 700 / 1 800; at 2 000 the HBM tags win, 111.9 against 116.9 ms; scripts/long_pool_probe.py)
-    const uint32_t lds_until = use_hub ? 1200u : dense ? 512u : 1950u;
+    // With the half-precision screen (200-d inner product) a hop is two dependent gathers of fewer bytes and the launch lives
+    // on resident workgroups, so the small table wins earlier and the HBM tags -- twelve workgroups per CU -- take over
+    // earlier: T2I-10M default graph, 10 000 queries, 8 192 / 4 096 / 2 048 tags / HBM tags: L_pq = 100 4.45 / 4.43 / 4.60 / 6.00 ms,
+    // 200 8.89 / 8.31 / 8.80 / 11.1, 500 24.9 / 20.5 / 22.0 / 25.5, 1 000 60.1 / 44.4 / 45.0 / 48.0, 1 400 87.9 / 71.7 / 66.4 / 66.6,
+    // 2 000 158 / 136 / 121 / 96.7 ms (scripts/quick_probe.py, profiles/r03_screen_forms.txt).
+    const bool screen_sparse = p.screen != nullptr && !dense && !use_hub;
+    const uint32_t lds_until = screen_sparse ? 1300u : use_hub ? 1200u : dense ? 512u : 1950u;
     int mode = idx->visited_mode == ROAR_VISITED_AUTO
                    ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                    : idx->visited_mode;
@@ -627,6 +633,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // workgroups per CU instead of seven (SIFT-1M shape, L_pq = 170, 2 048 / 4 096 / 8 192 / 16 384 tags: 6.94 / 6.31 / 6.99 /
         // 10.03 ms with 8 184 / 7 218 / 6 645 / 6 473 scored rows per query)
         if (!use_hub && !dense && idx->dim_pad * 4u < 768u) want = 4096u;
+        if (screen_sparse) want = L < 150 ? 8192u : 4096u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
         else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
@@ -758,8 +765,11 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // L_pq = 55 0.973 / 0.997 / 0.970 / 1.021 ms).  EXACT mode wants every wave it can get (its tag probes are latency).
     // Rows of 768 bytes and more only: with 512-byte rows (SIFT-1M shape, L_pq = 170, 28 fresh rows per hop) a wave has too
     // little in flight and the seventh workgroup is worth 13 % (1.34 -> 1.51 M QPS).
+    // With the half-precision screen a hop is two dependent gathers of fewer bytes: the launch is bound by latency again and takes
+    // every workgroup the LDS allows (T2I-10M, 10 000 queries, 6 / 7 / 8 per CU: L_pq = 50 2.73 / 2.57 / 2.48 ms, 100 5.39 / 4.83 /
+    // 4.43 ms, 200 10.1 / 9.0 / 9.0 ms).
     if (idx->waves_per_cu == 0 && mode == ROAR_VISITED_LDS && sel.waves == 1 && !bipartite && !idx->building &&
-        idx->dim_pad * 4u >= 768u)
+        idx->dim_pad * 4u >= 768u && !p.screen)
         wpc = std::min(wpc, 6);
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
     if (grid > nq) grid = nq;

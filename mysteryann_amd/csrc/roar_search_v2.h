@@ -357,6 +357,7 @@ __device__ __forceinline__ uint32_t screen_rows(const unsigned char *__restrict_
                                                 float qnorm, int lane) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
+    // (three rows per lane group and pass -- 48 rows in flight -- spill registers to scratch and measure no faster)
     for (; p0 + 16 < m; p0 += 32) screen_pass<2>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
     for (; p0 < m; p0 += 16) screen_pass<1>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
     return w;

@@ -135,7 +135,8 @@ struct roar_index {
     // half-precision screening copy of a 200-d inner-product base set (RoarSearchParams::screen), n x 416 bytes, made on first use
     unsigned char *screen = nullptr;
     uint64_t screen_n = 0;
-    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it), 1 off
+    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it: 8-bit codes), 1 off, 16 half precision, 8 8-bit codes
+    uint32_t screen_bits = 0;  // what `screen` holds
     int last_screen = 0;
     uint64_t n = 0;
     uint32_t ld = 0;
@@ -490,16 +491,19 @@ int ensure_hub_rows(roar_index *idx) {
 // The screening copy (roar_search_v2.h, screen_pass): + n x 416 bytes of HBM, one conversion pass.  Failure to make it is not an
 // error: the launch then scores every neighbour on the f32 rows, as without it.
 void ensure_screen(roar_index *idx) {
-    if (idx->screen && idx->screen_n == idx->n) return;
+    const uint32_t bits = idx->screen_mode == 16 ? 16u : 8u;
+    if (idx->screen && idx->screen_n == idx->n && idx->screen_bits == bits) return;
     if (idx->screen) (void)hipFree(idx->screen);
     idx->screen = nullptr;
     idx->screen_n = 0;
-    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * 416 + 256) != hipSuccess) {
+    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * (bits == 16 ? 416 : 256) + 256) != hipSuccess) {
         (void)hipGetLastError();
         idx->screen = nullptr;
         return;
     }
-    int rc = roar_launch_make_screen(idx->base, idx->ld, idx->n, idx->screen, nullptr);
+    idx->screen_bits = bits;
+    int rc = bits == 16 ? roar_launch_make_screen(idx->base, idx->ld, idx->n, idx->screen, nullptr)
+                        : roar_launch_make_screen8(idx->base, idx->ld, idx->n, idx->screen, nullptr);
     hipError_t e = rc == 0 ? hipDeviceSynchronize() : (hipError_t)rc;
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -538,9 +542,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.ld = idx->ld;
     p.dim = idx->dim_pad;
     idx->last_screen = 0;
-    if (!bipartite && idx->ip && idx->dim_pad == 200 && idx->screen_mode == 0) {
+    if (!bipartite && idx->ip && idx->dim_pad == 200 && idx->screen_mode != 1) {
         ensure_screen(idx);
         p.screen = idx->screen;
+        p.screen_bits = idx->screen_bits;
         idx->last_screen = idx->screen ? 1 : 0;
     }
     p.adj = idx->adj;
@@ -583,11 +588,12 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (sparse graph, L_pq 1 500 ... 1 900: a 4 096-tag table with six workgroups per CU re-scores 50 % more rows than the
     // reference and still beats the HBM tags, 82.1 / 87.6 / 93.1 / 98.5 ms against 85.1 / 91.5 / 96.1 / 101.0 ms at L_pq = 1 500 /
     // 1 600 / 1 700 / 1 800; at 2 000 the HBM tags win, 111.9 against 116.9 ms; scripts/long_pool_probe.py)
-    // With the half-precision screen (200-d inner product) a hop is two dependent gathers of fewer bytes and the launch lives
-    // on resident workgroups, so the small table wins earlier and the HBM tags -- twelve workgroups per CU -- take over
-    // earlier: T2I-10M default graph, 10 000 queries, 8 192 / 4 096 / 2 048 tags / HBM tags: L_pq = 100 4.45 / 4.43 / 4.60 / 6.00 ms,
-    // 200 8.89 / 8.31 / 8.80 / 11.1, 500 24.9 / 20.5 / 22.0 / 25.5, 1 000 60.1 / 44.4 / 45.0 / 48.0, 1 400 87.9 / 71.7 / 66.4 / 66.6,
-    // 2 000 158 / 136 / 121 / 96.7 ms (scripts/quick_probe.py, profiles/r03_screen_forms.txt).
+    // With the 8-bit screen (200-d inner product) a hop is two dependent gathers of far fewer bytes and the launch lives on
+    // resident workgroups: the small tables win everywhere (twelve workgroups per CU, the register limit) and the HBM tags --
+    // also twelve per CU -- take over earlier.  T2I-10M default graph, 10 000 queries, 8 192 / 4 096 / 2 048 tags / HBM tags:
+    // L_pq = 50 2.15 / 1.81 / 1.83 / 3.04 ms, 100 4.31 / 3.50 / 3.62 / 5.57, 200 8.99 / 6.82 / 6.85 / 10.3, 500 25.8 / 19.9 / 17.4 / 23.9,
+    // 1 000 63.8 / 43.5 / 38.5 / 45.1, 1 400 92.9 / 73.1 / 64.2 / 61.8, 2 000 165 / 142 / 122 / 91.3 ms (scripts/quick_probe.py,
+    // profiles/r03_screen_forms.txt).
     const bool screen_sparse = p.screen != nullptr && !dense && !use_hub;
     const uint32_t lds_until = screen_sparse ? 1300u : use_hub ? 1200u : dense ? 512u : 1950u;
     int mode = idx->visited_mode == ROAR_VISITED_AUTO
@@ -633,7 +639,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // workgroups per CU instead of seven (SIFT-1M shape, L_pq = 170, 2 048 / 4 096 / 8 192 / 16 384 tags: 6.94 / 6.31 / 6.99 /
         // 10.03 ms with 8 184 / 7 218 / 6 645 / 6 473 scored rows per query)
         if (!use_hub && !dense && idx->dim_pad * 4u < 768u) want = 4096u;
-        if (screen_sparse) want = L < 150 ? 8192u : 4096u;
+        if (screen_sparse) want = L < 300 ? 4096u : 2048u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
         else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
@@ -662,7 +668,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_vis = off;
     off += 2 * entries;
     p.off_ctrl = off;
-    off += bp_wg ? 64 : 32;
+    off += 64;  // (words 0-5 multi-wave hand-over, 6 spill epoch, 8-9 query norm / sum for the screen)
     if (use_hub) {  // row buffer + bitmap of the hub form
         p.off_rowbuf = off;
         off += 1024;
@@ -765,9 +771,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // L_pq = 55 0.973 / 0.997 / 0.970 / 1.021 ms).  EXACT mode wants every wave it can get (its tag probes are latency).
     // Rows of 768 bytes and more only: with 512-byte rows (SIFT-1M shape, L_pq = 170, 28 fresh rows per hop) a wave has too
     // little in flight and the seventh workgroup is worth 13 % (1.34 -> 1.51 M QPS).
-    // With the half-precision screen a hop is two dependent gathers of fewer bytes: the launch is bound by latency again and takes
-    // every workgroup the LDS allows (T2I-10M, 10 000 queries, 6 / 7 / 8 per CU: L_pq = 50 2.73 / 2.57 / 2.48 ms, 100 5.39 / 4.83 /
-    // 4.43 ms, 200 10.1 / 9.0 / 9.0 ms).
+    // With the screen a hop is two dependent gathers of fewer bytes: the launch is bound by latency again and takes every
+    // workgroup the LDS and the registers allow.
     if (idx->waves_per_cu == 0 && mode == ROAR_VISITED_LDS && sel.waves == 1 && !bipartite && !idx->building &&
         idx->dim_pad * 4u >= 768u && !p.screen)
         wpc = std::min(wpc, 6);
@@ -2519,7 +2524,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
         idx->hub_mode = (int)value;
     } else if (k == "screen") {
-        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "screen must be 0 (auto) or 1 (off)");
+        if (value != 0 && value != 1 && value != 8 && value != 16) return fail(ROAR_ERR_ARG, "screen must be 0 (auto), 1 (off), 8 or 16");
         idx->screen_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");

@@ -437,6 +437,45 @@ __global__ void __launch_bounds__(256) roar_make_screen_kernel(const float *__re
     }
 }
 
+// 8-bit screening copy of 200-d rows (roar_search_v2.h, screen8_pass): one wave per row, lane l < 50 owns floats 4l .. 4l+3.
+// s = max|x| / 127, c_i = rint(x_i / s) clamped to [-127, 127], u_i = c_i + 128; e = |x - s c|_2 evaluated in f32 and rounded up;
+// bytes 200..203 = s, 204..207 = B = 1.001 e + 0.07 s.  A row with a non-finite component gets B = +inf (never screened out).
+__global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, u64 n, unsigned char *__restrict__ out) {
+    const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const float *row = base + v * ld;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 50) a = reinterpret_cast<const float4 *>(row)[lane];
+    float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fmaxf(__builtin_fabsf(a.z), __builtin_fabsf(a.w)));
+    bool bad = !(mx <= 3.0e38f);  // inf or NaN (fmaxf drops NaNs: test the components)
+    bad |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    const bool anybad = __ballot(bad) != 0;
+    const float sc = mx / 127.0f;
+    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    const float f[4] = {a.x, a.y, a.z, a.w};
+    uint32_t word = 0;
+    float e2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float c = __builtin_rintf(f[i] * inv);
+        c = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, c));
+        const float d = f[i] - sc * c;
+        e2 = __builtin_fmaf(d, d, e2);
+        word |= (uint32_t)((int)c + 128) << (8 * i);
+    }
+    if (lane >= 50) e2 = 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * 256);
+    if (lane < 50) o32[lane] = anybad ? 0x80808080u : word;
+    if (lane == 50) o32[50] = __float_as_uint(anybad ? 0.f : sc);
+    if (lane == 51) o32[51] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * __builtin_sqrtf(e2) * 1.0001f + 0.07f * sc);
+    if (lane >= 52) o32[lane] = 0u;
+}
+
 // local ids of a shard -> global ids (index-sharded configuration); "no result" stays "no result"
 __global__ void roar_rebase_ids_kernel(uint32_t *__restrict__ ids, u64 count, uint32_t base) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,6 +668,12 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
 extern "C" int roar_launch_make_screen(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(roar_make_screen_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, (u64)n, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, (u64)n, out);
     return (int)hipGetLastError();
 }
 

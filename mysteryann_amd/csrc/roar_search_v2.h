@@ -294,15 +294,41 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
 // -- which the merge would have rejected (neighbor.h:151-153).  Everything else goes on to the exact pass, whose distances,
 // keys and merges are the ones of the reference, bit for bit.  cmps counts the neighbours BEFORE the screen, as the reference
 // counts its distance evaluations.  (The threshold is read before the hop's merges: it can only be looser than the reference's.)
-constexpr uint32_t SCREEN_STRIDE = 416;  // bytes per screening row: 26 chunks of 16 bytes
-#define ROAR_SCREEN_EPS 5.04e-4f          // 2^-11 + 2^-16, rounded up
-#define ROAR_SCREEN_TINY 4.3e-7f          // sqrt(200) * 2^-25, rounded up
+// ---- the same screen on 8-bit codes: TWO lines per row ----------------------------------------------------------------------
+// Row of 256 bytes (two whole lines): bytes 0..199 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then
+// s = max|x| / 127 (f32) and B (f32).  With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2 (the quantisation error of THIS
+// row, computed when the copy is made); the kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32, whose rounding is below
+// 0.07 s |q| (gamma_200 (255 + 128) |q|_1 s + the final operations, |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.07 s, so the
+// exact distance of the row is >= -(screened dot) - |q| B.  A row of zeros has s = 0, B = 0: its screened value is exact.
+constexpr uint32_t SCREEN8_STRIDE = 256;
+
+__device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, float acc) {
+    const float4 q0 = *reinterpret_cast<const float4 *>(lq16), q1 = *reinterpret_cast<const float4 *>(lq16 + 4),
+                 q2 = *reinterpret_cast<const float4 *>(lq16 + 8), q3 = *reinterpret_cast<const float4 *>(lq16 + 12);
+    acc = __builtin_fmaf((float)(v.x & 0xFFu), q0.x, acc);
+    acc = __builtin_fmaf((float)((v.x >> 8) & 0xFFu), q0.y, acc);
+    acc = __builtin_fmaf((float)((v.x >> 16) & 0xFFu), q0.z, acc);
+    acc = __builtin_fmaf((float)(v.x >> 24), q0.w, acc);
+    acc = __builtin_fmaf((float)(v.y & 0xFFu), q1.x, acc);
+    acc = __builtin_fmaf((float)((v.y >> 8) & 0xFFu), q1.y, acc);
+    acc = __builtin_fmaf((float)((v.y >> 16) & 0xFFu), q1.z, acc);
+    acc = __builtin_fmaf((float)(v.y >> 24), q1.w, acc);
+    acc = __builtin_fmaf((float)(v.z & 0xFFu), q2.x, acc);
+    acc = __builtin_fmaf((float)((v.z >> 8) & 0xFFu), q2.y, acc);
+    acc = __builtin_fmaf((float)((v.z >> 16) & 0xFFu), q2.z, acc);
+    acc = __builtin_fmaf((float)(v.z >> 24), q2.w, acc);
+    acc = __builtin_fmaf((float)(v.w & 0xFFu), q3.x, acc);
+    acc = __builtin_fmaf((float)((v.w >> 8) & 0xFFu), q3.y, acc);
+    acc = __builtin_fmaf((float)((v.w >> 16) & 0xFFu), q3.z, acc);
+    acc = __builtin_fmaf((float)(v.w >> 24), q3.w, acc);
+    return acc;
+}
 
 template <int RR>
-__device__ __forceinline__ void screen_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
-                                            float thr_d, float qnorm, uint32_t &w, int t, int g) {
+__device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
+                                             float thr_d, float qnorm, float qsum128, uint32_t &w, int t, int g) {
     uint32_t id[RR];
-    uint4 x[RR][7];
+    uint4 x[RR][4];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const uint32_t c = p0 + 16 * r + g;
@@ -310,10 +336,10 @@ __device__ __forceinline__ void screen_pass(const unsigned char *__restrict__ sc
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
-        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * SCREEN_STRIDE);
+        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * SCREEN8_STRIDE);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) x[r][j] = row[t + 4 * j];  // chunks t, t + 4, ..., t + 20: data for every lane
-        x[r][6] = row[(t & 1) ? 25 : 24];                      // lanes 0 / 2: chunk 24 (data, used by lane 0); lanes 1 / 3: the norm chunk
+        for (int j = 0; j < 3; ++j) x[r][j] = row[t + 4 * j];  // chunks t, t + 4, t + 8 (16 codes each)
+        x[r][3] = row[12];                                      // codes 192..199, s, B (used by lane 0)
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
@@ -322,25 +348,28 @@ __device__ __forceinline__ void screen_pass(const unsigned char *__restrict__ sc
     for (int r = 0; r < RR; ++r) {
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int c = (j == 6) ? 24 : t + 4 * j;
-            const float4 qa = *reinterpret_cast<const float4 *>(lq + 8 * c), qb = *reinterpret_cast<const float4 *>(lq + 8 * c + 4);
-            // (chunk 24 belongs to lane 0; the other lanes hold something else in that register and add zeros)
-            const uint4 v = (j == 6 && t != 0) ? make_uint4(0, 0, 0, 0) : x[r][j];
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))), qa.x, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.x >> 16))), qa.y, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))), qa.z, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.y >> 16))), qa.w, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.z & 0xFFFFu))), qb.x, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.z >> 16))), qb.y, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.w & 0xFFFFu))), qb.z, acc);
-            acc = __builtin_fmaf(__half2float(__ushort_as_half((unsigned short)(v.w >> 16))), qb.w, acc);
+        for (int j = 0; j < 3; ++j) {
+            acc = dot16_u8(x[r][j], lq + 16 * (t + 4 * j), acc);
+            __builtin_amdgcn_sched_barrier(0);  // (one chunk's query fragments at a time: hoisting them all costs registers)
         }
-        float xn = __uint_as_float(x[r][6].x);  // (meaningful in lanes 1 and 3)
+        {  // the last 8 codes: lane 0 only (the other lanes add zeros)
+            const uint4 v = x[r][3];
+            const float4 qa = *reinterpret_cast<const float4 *>(lq + 192), qb = *reinterpret_cast<const float4 *>(lq + 196);
+            float a2 = 0.f;
+            a2 = __builtin_fmaf((float)(v.x & 0xFFu), qa.x, a2);
+            a2 = __builtin_fmaf((float)((v.x >> 8) & 0xFFu), qa.y, a2);
+            a2 = __builtin_fmaf((float)((v.x >> 16) & 0xFFu), qa.z, a2);
+            a2 = __builtin_fmaf((float)(v.x >> 24), qa.w, a2);
+            a2 = __builtin_fmaf((float)(v.y & 0xFFu), qb.x, a2);
+            a2 = __builtin_fmaf((float)((v.y >> 8) & 0xFFu), qb.y, a2);
+            a2 = __builtin_fmaf((float)((v.y >> 16) & 0xFFu), qb.z, a2);
+            a2 = __builtin_fmaf((float)(v.y >> 24), qb.w, a2);
+            acc += (t == 0) ? a2 : 0.f;
+        }
         acc += quad_xor1(acc);
-        acc += quad_xor2(acc);                  // the four lanes' partial sums, in every lane of the group
-        xn = quad_xor1(xn);                     // lane 0 takes lane 1's word
-        const float lower = -acc - qnorm * __builtin_fmaf(ROAR_SCREEN_EPS, xn, ROAR_SCREEN_TINY);  // exact distance >= lower
+        acc += quad_xor2(acc);
+        const float sc = __uint_as_float(x[r][3].z), bnd = __uint_as_float(x[r][3].w);
+        const float lower = -(sc * (acc - qsum128)) - qnorm * bnd;  // the exact distance is >= lower
         const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
         bm[r] = __ballot(keep);
     }
@@ -352,14 +381,13 @@ __device__ __forceinline__ void screen_pass(const unsigned char *__restrict__ sc
     wave_sync();
 }
 
-// cid[0..m) -> the ids that may still have a key under the threshold, compacted in place (order kept); returns how many
-__device__ __forceinline__ uint32_t screen_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
-                                                float qnorm, int lane) {
+__device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
+                                                 float qnorm, float qsum128, int lane) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
-    // (three rows per lane group and pass -- 48 rows in flight -- spill registers to scratch and measure no faster)
-    for (; p0 + 16 < m; p0 += 32) screen_pass<2>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
-    for (; p0 < m; p0 += 16) screen_pass<1>(scr, lq, cid, p0, m, thr_d, qnorm, w, t, g);
+    // (four rows per lane group and pass -- a whole hop in one round trip -- do not fit the registers beside the hop's state)
+    for (; p0 + 16 < m; p0 += 32) screen8_pass<2>(scr, lq, cid, p0, m, thr_d, qnorm, qsum128, w, t, g);
+    for (; p0 < m; p0 += 16) screen8_pass<1>(scr, lq, cid, p0, m, thr_d, qnorm, qsum128, w, t, g);
     return w;
 }
 
@@ -474,14 +502,27 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         }
         block_sync();
 
-        float qnorm = 0.f;  // |q|, rounded up (screen_pass)
+        // |q| rounded up and 128 * sum q_i (screen8_pass): kept in LDS (ctrl[8], ctrl[9]), not in registers through the hop
         if constexpr (IP && NCH == 12 && TAIL) {
             if (wid == 0) {
-                float s2 = 0.f;
-                for (uint32_t i = lane; i < p.dim; i += 64) s2 = __builtin_fmaf(lq[i], lq[i], s2);
+                float qnorm, qsum128;
+                float s2 = 0.f, s1 = 0.f;
+                for (uint32_t i = lane; i < p.dim; i += 64) {
+                    s2 = __builtin_fmaf(lq[i], lq[i], s2);
+                    s1 += lq[i];
+                }
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+                for (int o = 32; o >= 1; o >>= 1) {
+                    s2 += __shfl_xor(s2, o, 64);
+                    s1 += __shfl_xor(s1, o, 64);
+                }
                 qnorm = __builtin_sqrtf(s2) * 1.0001f;
+                qsum128 = 128.f * s1;
+                if (lane == 0) {
+                    ctrl[8] = __float_as_uint(qnorm);
+                    ctrl[9] = __float_as_uint(qsum128);
+                }
+                wave_sync();
             }
         }
         // state of the sequential part (wave 0).  Pool: `pk` (register form, L_pq <= 64) or pool[] in LDS with the
@@ -677,7 +718,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             if (scr) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
-                                m = screen_rows(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), qnorm, lane);
+                                m = screen8_rows(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), lane);
                             }
                         }
                     }

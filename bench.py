@@ -505,6 +505,7 @@ def main():
     bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
+    screened = bool(idx.info("last_screen"))
     result = {
         "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD" if (args.workload, args.n) == ("t2i", 10_000_000)
         else f"QPS @ recall@10={args.target_recall}, {args.workload} shape",
@@ -531,7 +532,9 @@ def main():
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),
                    "visited": visited_desc,
-                   "half_precision_screen": bool(idx.info("last_screen")),
+                   "screen": ("8-bit codes of the base rows (256 B per row) scored first; a neighbour is dropped there only if its exact key is "
+                              "certainly above the reject threshold; the others are scored on the f32 rows: ids, distances, hops, cmps unchanged")
+                   if idx.info("last_screen") else "off",
                    "waves_per_query": idx.info("last_waves_per_query"), "register_pool": bool(idx.info("last_register_pool")),
                    "builder": args.builder, "index": index_desc, "graph_hash": f"{graph_hash:016x}",
                    "avg_degree": idx.info("nedges") / args.n, "adjacency_stride_words": idx.info("adj_stride"),
@@ -567,6 +570,11 @@ def main():
             tr = measure_traffic(args, idx, chosen, mine)
             if tr:
                 result["roofline"].update(tr)
+                # `achieved` / `frac` price the launch in the REFERENCE algorithm's bytes (4 D per distance evaluation), so
+                # they can exceed the peak when the screen keeps most f32 rows from being read at all; the bytes the launch really
+                # asked the memory side for, over the same time, are these:
+                result["roofline"]["requested_bytes_rate_GBs"] = tr["traffic"] / (kernel_ms * 1e-3) / 1e9
+                result["roofline"]["requested_bytes_frac_of_peak"] = tr["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 log(f"[rank 0] PMC traffic per launch {tr['traffic'] / 1e9:.2f} GB = {tr['traffic'] / bytes_per_launch:.3f} x algorithmic "
                     f"({time.time() - t0:.0f}s for the two profiled child passes)")
         except Exception as e:  # noqa: BLE001

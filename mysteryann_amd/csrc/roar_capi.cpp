@@ -132,11 +132,10 @@ struct roar_index {
     // base rows in HBM
     float *base = nullptr;
     bool base_owned = false;
-    // half-precision screening copy of a 200-d inner-product base set (RoarSearchParams::screen), n x 416 bytes, made on first use
+    // 8-bit screening copy of a 200-d inner-product base set (RoarSearchParams::screen), n x 256 bytes, made on first use
     unsigned char *screen = nullptr;
     uint64_t screen_n = 0;
-    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it: 8-bit codes), 1 off, 16 half precision, 8 8-bit codes
-    uint32_t screen_bits = 0;  // what `screen` holds
+    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it), 1 off
     int last_screen = 0;
     uint64_t n = 0;
     uint32_t ld = 0;
@@ -488,22 +487,19 @@ int ensure_hub_rows(roar_index *idx) {
     return ROAR_OK;
 }
 
-// The screening copy (roar_search_v2.h, screen_pass): + n x 416 bytes of HBM, one conversion pass.  Failure to make it is not an
+// The screening copy (roar_search_v2.h, screen8_pass): + n x 256 bytes of HBM, one conversion pass.  Failure to make it is not an
 // error: the launch then scores every neighbour on the f32 rows, as without it.
 void ensure_screen(roar_index *idx) {
-    const uint32_t bits = idx->screen_mode == 16 ? 16u : 8u;
-    if (idx->screen && idx->screen_n == idx->n && idx->screen_bits == bits) return;
+    if (idx->screen && idx->screen_n == idx->n) return;
     if (idx->screen) (void)hipFree(idx->screen);
     idx->screen = nullptr;
     idx->screen_n = 0;
-    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * (bits == 16 ? 416 : 256) + 256) != hipSuccess) {
+    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * 256 + 256) != hipSuccess) {
         (void)hipGetLastError();
         idx->screen = nullptr;
         return;
     }
-    idx->screen_bits = bits;
-    int rc = bits == 16 ? roar_launch_make_screen(idx->base, idx->ld, idx->n, idx->screen, nullptr)
-                        : roar_launch_make_screen8(idx->base, idx->ld, idx->n, idx->screen, nullptr);
+    int rc = roar_launch_make_screen8(idx->base, idx->ld, idx->n, idx->screen, nullptr);
     hipError_t e = rc == 0 ? hipDeviceSynchronize() : (hipError_t)rc;
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -545,7 +541,6 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     if (!bipartite && idx->ip && idx->dim_pad == 200 && idx->screen_mode != 1) {
         ensure_screen(idx);
         p.screen = idx->screen;
-        p.screen_bits = idx->screen_bits;
         idx->last_screen = idx->screen ? 1 : 0;
     }
     p.adj = idx->adj;
@@ -2524,7 +2519,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
         idx->hub_mode = (int)value;
     } else if (k == "screen") {
-        if (value != 0 && value != 1 && value != 8 && value != 16) return fail(ROAR_ERR_ARG, "screen must be 0 (auto), 1 (off), 8 or 16");
+        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "screen must be 0 (auto) or 1 (off)");
         idx->screen_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");

@@ -8,10 +8,9 @@ struct RoarSearchParams {
     const float *base;
     uint64_t ld;
     uint32_t dim;
-    // SearchRoarGraph kernels, 200-d inner product only: half-precision screening copy of the base rows, 416 bytes per row (25
-    // chunks of 8 halfs + one chunk whose first word is an upper bound of the row's norm; roar_launch_make_screen); null = off
+    // SearchRoarGraph kernels, 200-d inner product only: the 8-bit screening copy of the base rows, 256 bytes per row (200 codes,
+    // scale, error bound; roar_launch_make_screen8, roar_search_v2.h screen8_pass); null = off
     const unsigned char *screen;
-    uint32_t screen_bits;  // 16: the half-precision rows above; 8: 8-bit codes, 256 bytes per row (roar_launch_make_screen8)
     // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
     const uint32_t *adj;
     uint32_t adj_stride;
@@ -101,8 +100,7 @@ int roar_launch_search(const RoarSearchParams *p, const RoarKernelSel *sel, uint
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
-// f32 rows of 200 floats at stride ld -> screening rows (see RoarSearchParams::screen); out: n x 416 bytes
-int roar_launch_make_screen(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream);
+// f32 rows of 200 floats at stride ld -> screening rows (see RoarSearchParams::screen); out: n x 256 bytes
 int roar_launch_make_screen8(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream);
 int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
 // Max resident workgroups per CU for the selected kernel at this LDS size.

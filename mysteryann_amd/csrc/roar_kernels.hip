@@ -403,40 +403,6 @@ __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams 
     }
 }
 
-// Screening copy of 200-d rows (roar_search_v2.h, screen_pass): one wave per row.  Lane l < 25 converts floats 8l .. 8l+7 to halfs
-// (round to nearest even) and writes chunk l; the wave sums the squares; lane 25 writes the norm chunk: an upper bound of |x| --
-// +inf if a component does not survive the conversion (|x_i| beyond the half range, or not finite).
-__global__ void __launch_bounds__(256) roar_make_screen_kernel(const float *__restrict__ base, u64 ld, u64 n, unsigned char *__restrict__ out) {
-    const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63;
-    if (v >= n) return;
-    const float *row = base + v * ld;
-    float s2 = 0.f;
-    bool bad = false;
-    uint4 pk = make_uint4(0, 0, 0, 0);
-    if (lane < 25) {
-        const float4 a = reinterpret_cast<const float4 *>(row)[2 * lane], b = reinterpret_cast<const float4 *>(row)[2 * lane + 1];
-        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint32_t h[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            s2 = __builtin_fmaf(f[i], f[i], s2);
-            bad |= !(__builtin_fabsf(f[i]) <= 65000.0f);  // (also catches NaN)
-            h[i] = (uint32_t)__half_as_ushort(__float2half_rn(f[i]));
-        }
-        pk = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-    const bool anybad = __ballot(bad) != 0;
-    uint4 *o4 = reinterpret_cast<uint4 *>(out + v * 416);
-    if (lane < 25) o4[lane] = pk;
-    if (lane == 25) {
-        const float nrm = anybad ? __builtin_inff() : __builtin_sqrtf(s2) * 1.0001f;
-        o4[25] = make_uint4(__float_as_uint(nrm), 0, 0, 0);
-    }
-}
-
 // 8-bit screening copy of 200-d rows (roar_search_v2.h, screen8_pass): one wave per row, lane l < 50 owns floats 4l .. 4l+3.
 // s = max|x| / 127, c_i = rint(x_i / s) clamped to [-127, 127], u_i = c_i + 128; e = |x - s c|_2 evaluated in f32 and rounded up;
 // bytes 200..203 = s, 204..207 = B = 1.001 e + 0.07 s.  A row with a non-finite component gets B = +inf (never screened out).
@@ -662,12 +628,6 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
         hipLaunchKernelGGL(roar_distance_kernel<true>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
     else
         hipLaunchKernelGGL(roar_distance_kernel<false>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
-    return (int)hipGetLastError();
-}
-
-extern "C" int roar_launch_make_screen(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(roar_make_screen_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, (u64)n, out);
     return (int)hipGetLastError();
 }
 

@@ -281,25 +281,21 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
     }
 }
 
-// ---- half-precision screening in front of the exact scoring (200-d inner-product shape) -----------------------------------
+// ---- 8-bit screening in front of the exact scoring (200-d inner-product shape) -----------------------------------------------
 // What a hop costs the memory system is counted in 128-byte line requests, and of the ~49 rows a hop scores
-// only ~6 have a key under the pool's reject threshold.  The index therefore keeps a second, half-precision copy of the base
-// rows -- 25 chunks of 8 halfs + one chunk whose first word is an upper bound of the row's Euclidean norm, 416 bytes = four
-// lines instead of seven -- and a hop first scores its unvisited neighbours on that copy.  For the exact distance d of a row
-// and its screened value d~ (f32 accumulation of q_i * half(x_i)):
-//     |d - d~| <= sum |q_i| |x_i - half(x_i)| + (rounding of 200 fused multiply-adds) <= |q| (EPS |x| + TINY),
-// EPS = 2^-11 (round-to-nearest half, normal range) + 2^-16 (gamma_200 of the f32 accumulation, generously), TINY covers halfs
-// in the subnormal range; a row with a component outside the half range carries the norm +inf.  A neighbour is dropped here
-// only if d~ - |q| (EPS |x| + TINY) > the threshold's distance, i.e. only if its exact key is certainly above the threshold
-// -- which the merge would have rejected (neighbor.h:151-153).  Everything else goes on to the exact pass, whose distances,
-// keys and merges are the ones of the reference, bit for bit.  cmps counts the neighbours BEFORE the screen, as the reference
-// counts its distance evaluations.  (The threshold is read before the hop's merges: it can only be looser than the reference's.)
-// ---- the same screen on 8-bit codes: TWO lines per row ----------------------------------------------------------------------
-// Row of 256 bytes (two whole lines): bytes 0..199 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then
-// s = max|x| / 127 (f32) and B (f32).  With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2 (the quantisation error of THIS
-// row, computed when the copy is made); the kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32, whose rounding is below
-// 0.07 s |q| (gamma_200 (255 + 128) |q|_1 s + the final operations, |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.07 s, so the
-// exact distance of the row is >= -(screened dot) - |q| B.  A row of zeros has s = 0, B = 0: its screened value is exact.
+// only ~6 have a key under the pool's reject threshold.  The index therefore keeps a second copy of the base rows in 8-bit
+// codes -- 256 bytes = TWO lines per row instead of seven -- and a hop first scores its unvisited neighbours on that copy.
+// Row: bytes 0..199 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then s = max|x| / 127 (f32) and B (f32).
+// With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2, the quantisation error of THIS row, evaluated when the copy is made.
+// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.07 s |q|
+// (gamma_200 (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.07 s, hence
+//     exact distance of the row  >=  -(screened dot) - |q| B,
+// and a neighbour is dropped here only if that lower bound is above the distance of the pool's last entry, i.e. only if its
+// exact key is certainly above the reject threshold -- which the merge would have rejected (neighbor.h:151-153).  Everything
+// else goes on to the exact pass, whose distances, keys and merges are the reference's, bit for bit.  cmps counts the
+// neighbours BEFORE the screen, as the reference counts its distance evaluations.  (The threshold is read before the hop's
+// merges: it can only be looser than the reference's.  A row of zeros has s = 0, B = 0: its screened value is exact.  A row with a
+// component that is not finite has B = +inf and is never dropped.)
 constexpr uint32_t SCREEN8_STRIDE = 256;
 
 __device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, float acc) {

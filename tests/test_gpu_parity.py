@@ -992,6 +992,54 @@ def test_device_builder_matches_the_survey_probe_of_the_compiled_reference(golde
     idx.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["exact", "lds", "forgetful"])
+def test_screening_pass_never_changes_a_result(mode, built_lib):
+    """The 8-bit screening copy (200-d inner product; option "screen") may only drop neighbours whose exact key is certainly
+    above the reject threshold: ids, distances, hops and cmps with it equal those without it and the CPU oracle's -- on
+    rows chosen to strain the bound: a wide dynamic range inside a row (one component 1e4 times the others: the codes of
+    the others are all zero), rows of zeros, duplicated rows (exact ties), tiny rows, rows scaled by 1e-20 / 1e+15, a zero
+    query, a query with one dominant component."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 6000, 200, 40
+    rng = np.random.default_rng(123)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base[100:400, 7] *= 1e4                      # one dominant component
+    base[400:420] = 0.0                          # zero rows
+    base[500:600] = base[600:700]                # duplicates: equal distances, ids break the tie
+    base[700:900] *= np.float32(1e-20)
+    base[900:1100] *= np.float32(1e15)
+    base[1100:1300] = np.float32(1e-42)          # subnormal components
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = 0.0
+    q[1] = 0.0
+    q[1, 7] = 3.0
+    q[2] *= np.float32(1e-10)
+    q[3] *= np.float32(1e10)
+    deg = rng.integers(20, 70, n)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(deg)
+    nbrs = rng.integers(0, n, int(off[-1])).astype(np.uint32)
+    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(5, off, nbrs)
+    idx.set_option("visited_mode", mode)
+    for L in (10, 50, 64, 65, 300):
+        o = oracle.search_batch(base, off, nbrs, 5, q, K, L, 1)
+        idx.set_option("screen", 1)
+        a = idx.SearchRoarGraphBatch(q, K, L)
+        assert idx.info("last_screen") == 0
+        idx.set_option("screen", 0)
+        b = idx.SearchRoarGraphBatch(q, K, L)
+        assert idx.info("last_screen") == 1
+        for key in ("ids", "dists", "hops") + (("cmps",) if mode != 3 else ()):
+            assert np.array_equal(a[key], o[key]), (L, key, "screen off")
+            assert np.array_equal(b[key], o[key]), (L, key, "screen on")
+        assert np.array_equal(a["cmps"], b["cmps"])
+    idx.close()
+
+
 def test_device_builder_refuses_lists_that_name_no_base_point(built_lib):
     """roar_build_roargraph_device reads the learn->base lists from the caller's HBM: an id outside the base set must be
     refused like the host form refuses it ("learn base knn file error"), not read or written out of bounds; a float tensor

@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams 
 
 // 8-bit screening copy of 200-d rows (roar_search_v2.h, screen8_pass): one wave per row, lane l < 50 owns floats 4l .. 4l+3.
 // s = max|x| / 127, c_i = rint(x_i / s) clamped to [-127, 127], u_i = c_i + 128; e = |x - s c|_2 evaluated in f32 and rounded up;
-// bytes 200..203 = s, 204..207 = B = 1.001 e + 0.07 s.  A row with a non-finite component gets B = +inf (never screened out).
+// bytes 200..203 = s, 204..207 = B = 1.001 e + 0.08 s.  A row with a non-finite component gets B = +inf (never screened out).
 __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, u64 n, unsigned char *__restrict__ out) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
     uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * 256);
     if (lane < 50) o32[lane] = anybad ? 0x80808080u : word;
     if (lane == 50) o32[50] = __float_as_uint(anybad ? 0.f : sc);
-    if (lane == 51) o32[51] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * __builtin_sqrtf(e2) * 1.0001f + 0.07f * sc);
+    if (lane == 51) o32[51] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * __builtin_sqrtf(e2) * 1.0001f + 0.08f * sc);
     if (lane >= 52) o32[lane] = 0u;
 }
 

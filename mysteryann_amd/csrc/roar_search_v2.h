@@ -287,8 +287,8 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
 // codes -- 256 bytes = TWO lines per row instead of seven -- and a hop first scores its unvisited neighbours on that copy.
 // Row: bytes 0..199 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then s = max|x| / 127 (f32) and B (f32).
 // With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2, the quantisation error of THIS row, evaluated when the copy is made.
-// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.07 s |q|
-// (gamma_200 (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.07 s, hence
+// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.065 s |q|
+// (gamma_200 (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.08 s, hence
 //     exact distance of the row  >=  -(screened dot) - |q| B,
 // and a neighbour is dropped here only if that lower bound is above the distance of the pool's last entry, i.e. only if its
 // exact key is certainly above the reject threshold -- which the merge would have rejected (neighbor.h:151-153).  Everything

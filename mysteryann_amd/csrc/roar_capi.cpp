@@ -136,6 +136,7 @@ struct roar_index {
     unsigned char *screen = nullptr;
     uint64_t screen_n = 0;
     int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it), 1 off
+    int launch_events = 1;  // option "launch_events": 0 = no timing events around a launch ("last_kernel_ns" then keeps its last value)
     int last_screen = 0;
     uint64_t n = 0;
     uint32_t ld = 0;
@@ -1702,11 +1703,14 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
         HIP_TRY(hipStreamWaitEvent(st, idx->ev1, 0));
     idx->last_stream = st;
     idx->last_used_tags = plan.sel.visited_mode == ROAR_VISITED_EXACT || p.tags != nullptr;
-    HIP_TRY(hipEventRecord(idx->ev0, st));
+    const bool timed = idx->launch_events != 0 || p.tags != nullptr;  // (launches that share tag lists are ordered by ev1)
+    if (timed) HIP_TRY(hipEventRecord(idx->ev0, st));
     int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    HIP_TRY(hipEventRecord(idx->ev1, st));
-    idx->ev_valid = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(idx->ev1, st));
+        idx->ev_valid = true;
+    }
     return ROAR_OK;
 }
 
@@ -2518,6 +2522,8 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "hub_mode") {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
         idx->hub_mode = (int)value;
+    } else if (k == "launch_events") {
+        idx->launch_events = value ? 1 : 0;
     } else if (k == "screen") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "screen must be 0 (auto) or 1 (off)");
         idx->screen_mode = (int)value;
@@ -2562,6 +2568,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_register_pool") *value = idx->last_sel.regpool;
     else if (k == "last_hub_bitmap") *value = idx->last_sel.hub;
     else if (k == "last_screen") *value = idx->last_screen;
+    else if (k == "launch_events_on") *value = idx->launch_events;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;
     else if (k == "bipartite_edges") *value = (int64_t)idx->bp_edges;

@@ -399,6 +399,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
+    // (a build with R = 1 and four waves per SIMD for launches with the screen on -- sixteen workgroups per CU -- spills inside
+    // the hop and is 60 % slower: 2.94 against 1.83 ms at L_pq = 50; dropped)
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = (W == 1) ? 0 : (int)(threadIdx.x >> 6);
     u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);

@@ -11,7 +11,7 @@ L, K, B, STEPS = int(os.environ.get("L_PQ", "55")), 10, 8, 64
 idx, base, queries = t2i_index(10_000_000, 10_000 * B, "reference", 0, "/tmp/r3_graph2.index")
 dev = queries.device
 main = torch.cuda.current_stream(dev)
-side = [torch.cuda.Stream(dev) for _ in range(4)]
+side = [torch.cuda.Stream(dev) for _ in range(16)]
 
 
 def loop(batches, outs, depth):
@@ -29,7 +29,9 @@ def loop(batches, outs, depth):
 
 
 ref = None
-for g in (1, 2, 4, 8, 16):
+GS = [int(x) for x in os.environ.get("ONLY_N", "1,2,4,8,16").split(",")]
+DEPTHS = [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4,6,8").split(",")]
+for g in GS:
     nq = 10_000 // g
     batches = [queries[b * 10_000:b * 10_000 + nq].contiguous() for b in range(B)]
     outs = [idx.SearchRoarGraphBatchDevice(batches[b], K, L) for b in range(B)]
@@ -41,12 +43,14 @@ for g in (1, 2, 4, 8, 16):
         best = min(best, idx.info("last_kernel_ns") / 1e6)
     hops = torch.stack([o["hops"] for o in outs]).float()
     row = [f"N={g:2d} nq/GPU={nq:5d} grid {idx.info('last_grid'):4d} kernel {best:.4f} ms  hops mean {hops.mean():.1f} max {hops.max():.0f}"]
-    for depth, mg in ((1, 0), (2, 0), (3, 0)):
+    for depth, mg in [(x, 0) for x in DEPTHS]:  # negative: without the library's timing events
+        idx.set_option("launch_events", 1 if depth > 0 else 0)
+        depth = abs(depth)
         idx.set_option("max_grid", mg)
         ms = min(loop(batches, outs, depth) for _ in range(3))
         if g == 1 and depth == 1:
             ref = ms
-        row.append(f"in-flight {depth}" + (f" grid<={mg}" if mg else "") + f": {ms:.4f} ms/step ({ref / ms:.2f}x)")
+        row.append(f"in-flight {depth}" + ("" if idx.info("launch_events_on") else " (no events)") + f": {ms:.4f} ms/step ({ref / ms:.2f}x)")
     idx.set_option("max_grid", 0)
     row.append(f"host enqueue {loop.host_ms * 1e3:.0f} us/launch")
     loop.host_ms = 1e9

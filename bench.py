@@ -36,6 +36,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Launches of several steps overlap on several HIP streams (--in-flight): give the runtime as many hardware queues as streams
+# (its default is four per device; a launch can only start when the launch before it in the same hardware queue has finished
+# -- its slowest query -- so with four queues six streams of 1 250-query launches run at 0.270 ms per step, with eight at
+# 0.240 ms; scripts/scale_probe.py).  Read by the HIP runtime when it starts, i.e. before torch is imported; inherited by the
+# ranks this script starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 L_LIST = [10, 15, 20, 25, 30, 35, 40, 45, 50, 55, 60, 65, 70, 75, 80, 85, 90, 95, 100, 110, 120, 130, 140, 150, 160,
           170, 180, 190, 200, 220, 240, 260, 280, 300, 350, 400, 450, 500, 550, 600, 650, 700, 750, 800, 900, 1000,
@@ -154,10 +160,11 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=8,
                     help="distinct query batches rotated through the timed loop (same distribution, own draws), so that a "
                          "step never finds the rows of the step before it in the Infinity Cache")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=0,
                     help="launches in flight in the timed loop (step s on stream s mod IN_FLIGHT; each step its own batch and result "
-                         "buffers).  1 = one launch after the other.  The kernel's own duration (roofline) is always measured "
-                         "one launch at a time")
+                         "buffers).  1 = one launch after the other; 0 = by the size of a rank's share of the batch: 2 from 4 000 queries, "
+                         "4 from 2 000, 6 below (a small launch ends with its slowest query: the fewer queries, the more launches have to "
+                         "overlap to keep the chip full).  The kernel's own duration (roofline) is always measured one launch at a time")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = ONE nq-query batch per step, rank r searches rows [r nq/N, (r+1) nq/N) of it "
                          "(BASELINE configs[3]); weak = every rank searches its own nq-query batch")
@@ -440,7 +447,8 @@ def main():
     rec = float(np.mean(recalls))
 
     main_stream = torch.cuda.current_stream(dev)
-    side = [torch.cuda.Stream(dev) for _ in range(max(1, min(args.in_flight, B)))]
+    depth_wanted = args.in_flight if args.in_flight > 0 else (2 if mine >= 4000 else 4 if mine >= 2000 else 6)
+    side = [torch.cuda.Stream(dev) for _ in range(max(1, min(depth_wanted, B)))]
 
     def timed(order, in_flight=1):
         """`steps` launches, batch of step s = order(s); barrier + synchronize on both sides; -> (wall s max over ranks, gpu ms).

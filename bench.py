@@ -162,9 +162,10 @@ def parse_args(argv=None):
                          "step never finds the rows of the step before it in the Infinity Cache")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="launches in flight in the timed loop (step s on stream s mod IN_FLIGHT; each step its own batch and result "
-                         "buffers).  1 = one launch after the other; 0 = by the size of a rank's share of the batch: 2 from 4 000 queries, "
-                         "4 from 2 000, 6 below (a small launch ends with its slowest query: the fewer queries, the more launches have to "
+                         "buffers).  1 = one launch after the other; 0 = 6 (a launch ends with its slowest query: launches have to "
                          "overlap to keep the chip full).  The kernel's own duration (roofline) is always measured one launch at a time")
+    ap.add_argument("--launch-grid", type=int, default=-1,
+                    help="workgroups per launch while launches overlap (-1 = 1 024, 640 for a rank's share under 2 000 queries; 0 = no cap)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = ONE nq-query batch per step, rank r searches rows [r nq/N, (r+1) nq/N) of it "
                          "(BASELINE configs[3]); weak = every rank searches its own nq-query batch")
@@ -447,7 +448,7 @@ def main():
     rec = float(np.mean(recalls))
 
     main_stream = torch.cuda.current_stream(dev)
-    depth_wanted = args.in_flight if args.in_flight > 0 else (2 if mine >= 4000 else 4 if mine >= 2000 else 6)
+    depth_wanted = args.in_flight if args.in_flight > 0 else 6
     side = [torch.cuda.Stream(dev) for _ in range(max(1, min(depth_wanted, B)))]
     for st_ in side:  # a stream's hardware queue is made on its first use (milliseconds): not inside a timed loop
         run(chosen, 0, outs[0], st_)
@@ -507,8 +508,16 @@ def main():
     last_kernel_ms = idx.info("last_kernel_ns") * 1e-6      #   the kernel's own duration (roofline) comes from this loop
     kernel_ms = gpu_ms / args.steps
     depth = len(side)
+    pipe_grid = 0
     if depth > 1:                                           # THE measurement: the same K steps, `depth` launches in flight
+        # each launch of an overlapping stream of launches takes a share of the chip, not all of it: 1 024 workgroups (640 for
+        # the small launches of a rank's share at N = 8); six of them oversubscribe the 3 072 resident workgroups twice over,
+        # which is what keeps every slot busy while launches come and go (scripts/scale_probe.py: 10 000 queries 1.453 ms per
+        # step against 1.521 with two uncapped launches; 1 250 queries 0.211 against 0.225 ms)
+        pipe_grid = args.launch_grid if args.launch_grid >= 0 else (1024 if mine >= 2000 else 640)
+        idx.set_option("max_grid", pipe_grid)
         wall, gpu_pipe = timed(lambda s_: s_ % B, depth)
+        idx.set_option("max_grid", 0)
     else:
         wall, gpu_pipe = wall_serial, gpu_ms
     ms_per_step = wall * 1e3 / args.steps
@@ -537,7 +546,7 @@ def main():
                    "n_queries_per_gpu": mine, "k": args.k, "L_pq": chosen, "recall_at_10": rec,
                    "recall_at_10_min_over_batches": float(min(recalls)),
                    "query_batches_rotated": B, "ms_per_step_same_batch_replayed": wall_replay * 1e3 / args.steps,
-                   "launches_in_flight": depth, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
+                   "launches_in_flight": depth, "workgroups_per_launch_cap_in_flight": pipe_grid, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
                    "value_one_launch_at_a_time": total_q * args.steps / wall_serial,
                    "parallelism": (f"index replicated on {world} GPU(s); one {args.nq}-query batch per step split by query, "
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else

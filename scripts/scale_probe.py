@@ -44,14 +44,15 @@ for g in GS:
         best = min(best, idx.info("last_kernel_ns") / 1e6)
     hops = torch.stack([o["hops"] for o in outs]).float()
     row = [f"N={g:2d} nq/GPU={nq:5d} grid {idx.info('last_grid'):4d} kernel {best:.4f} ms  hops mean {hops.mean():.1f} max {hops.max():.0f}"]
-    for depth, mg in [(x, 0) for x in DEPTHS]:  # negative: without the library's timing events
+    MG = [int(x) for x in os.environ.get("MAXGRID", "0").split(",")]
+    for depth, mg in [(x, y) for x in DEPTHS for y in MG]:  # negative: without the library's timing events
         idx.set_option("launch_events", 1 if depth > 0 else 0)
         depth = abs(depth)
         idx.set_option("max_grid", mg)
         ms = min(loop(batches, outs, depth) for _ in range(3))
         if ref is None:
             ref = ms
-        row.append(f"in-flight {depth}" + ("" if idx.info("launch_events_on") else " (no events)") + f": {ms:.4f} ms/step ({ref / ms:.2f}x)")
+        row.append(f"in-flight {depth}" + (f" grid<={mg}" if mg else "") + ("" if idx.info("launch_events_on") else " (no events)") + f": {ms:.4f} ms/step ({ref / ms:.2f}x)")
     idx.set_option("max_grid", 0)
     row.append(f"host enqueue {loop.host_ms * 1e3:.0f} us/launch")
     loop.host_ms = 1e9

@@ -522,6 +522,21 @@ def main():
         wall, gpu_pipe = wall_serial, gpu_ms
     ms_per_step = wall * 1e3 / args.steps
     qps = total_q * args.steps / wall
+    # N > 1, strong scaling: the same K steps once more with every rank on WHOLE batches of its own (rank r starts the rotation at
+    # batch r): what the N GPUs serve when each has its own stream of 10 000-query batches (per-GPU work fixed = weak scaling),
+    # reported beside the strong figure.  Recall is not re-checked here (same index, same L_pq, same query distribution).
+    weak_value = None
+    if (world > 1 or os.environ.get("ROAR_BENCH_WEAK_SIDE")) and strong:  # (the variable: to exercise this loop on a one-GPU box)
+        full = [qall[b * args.nq:(b + 1) * args.nq].contiguous() for b in range(B)]
+        fouts = [idx.SearchRoarGraphBatchDevice(full[b], args.k, chosen) for b in range(B)]
+        torch.cuda.synchronize()
+        keep_b, keep_o = batches, outs
+        batches, outs = full, fouts  # (run() and timed() read these names)
+        idx.set_option("max_grid", 1024 if depth > 1 else 0)
+        wall_w, _ = timed(lambda s_: (s_ + rank) % B, depth)
+        idx.set_option("max_grid", 0)
+        batches, outs = keep_b, keep_o
+        weak_value = world * args.nq * args.steps / wall_w
     bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
@@ -546,7 +561,8 @@ def main():
                    "n_queries_per_gpu": mine, "k": args.k, "L_pq": chosen, "recall_at_10": rec,
                    "recall_at_10_min_over_batches": float(min(recalls)),
                    "query_batches_rotated": B, "ms_per_step_same_batch_replayed": wall_replay * 1e3 / args.steps,
-                   "launches_in_flight": depth, "workgroups_per_launch_cap_in_flight": pipe_grid, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
+                   "launches_in_flight": depth, "workgroups_per_launch_cap_in_flight": pipe_grid,
+                   "value_with_a_whole_batch_per_rank_and_step_weak_scaling": weak_value, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
                    "value_one_launch_at_a_time": total_q * args.steps / wall_serial,
                    "parallelism": (f"index replicated on {world} GPU(s); one {args.nq}-query batch per step split by query, "
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else

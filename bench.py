@@ -268,7 +268,19 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout is for the one JSON line, so the file
+        # descriptor points at stderr until that has happened
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     dev = torch.device("cuda", local)
 
     from mysteryann_amd import index as mi

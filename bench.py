@@ -165,7 +165,7 @@ def parse_args(argv=None):
                          "buffers).  1 = one launch after the other; 0 = 6 (a launch ends with its slowest query: launches have to "
                          "overlap to keep the chip full).  The kernel's own duration (roofline) is always measured one launch at a time")
     ap.add_argument("--launch-grid", type=int, default=-1,
-                    help="workgroups per launch while launches overlap (-1 = 1 024, 640 for a rank's share under 2 000 queries; 0 = no cap)")
+                    help="workgroups per launch while launches overlap (-1 = 1 024, 640 for a rank's share under 8 000 queries; 0 = no cap)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = ONE nq-query batch per step, rank r searches rows [r nq/N, (r+1) nq/N) of it "
                          "(BASELINE configs[3]); weak = every rank searches its own nq-query batch")
@@ -523,10 +523,10 @@ def main():
     pipe_grid = 0
     if depth > 1:                                           # THE measurement: the same K steps, `depth` launches in flight
         # each launch of an overlapping stream of launches takes a share of the chip, not all of it: 1 024 workgroups (640 for
-        # the small launches of a rank's share at N = 8); six of them oversubscribe the 3 072 resident workgroups twice over,
-        # which is what keeps every slot busy while launches come and go (scripts/scale_probe.py: 10 000 queries 1.453 ms per
-        # step against 1.521 with two uncapped launches; 1 250 queries 0.211 against 0.225 ms)
-        pipe_grid = args.launch_grid if args.launch_grid >= 0 else (1024 if mine >= 2000 else 640)
+        # a rank's share of the batch at N > 1); six of them oversubscribe the 3 072 resident workgroups, which is what keeps
+        # every slot busy while launches come and go (profiles/r03_scale_probe.txt: 10 000 queries 1.463 ms per step against
+        # 1.522 with two uncapped launches; 5 000 0.750 / 0.817; 2 500 0.389 / 0.466; 1 250 0.212 / 0.307 ms)
+        pipe_grid = args.launch_grid if args.launch_grid >= 0 else (1024 if mine >= 8000 else 640)
         idx.set_option("max_grid", pipe_grid)
         wall, gpu_pipe = timed(lambda s_: s_ % B, depth)
         idx.set_option("max_grid", 0)

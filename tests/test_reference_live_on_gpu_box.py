@@ -62,6 +62,7 @@ def test_hip_search_equals_reference_components_directly(built_lib, golden_dir):
         idx = mi.IndexBipartite(d, n, metric, None)
         idx.SetBaseData(base)
         idx.SetProjectionGraph(5, off, nbrs)
+        idx.set_option("visited_mode", 1)  # the exact on-chip form: cmps is the reference's too (AUTO may take the forgetful one)
         for L in (10, 64, 300):
             r = idx.SearchRoarGraphBatch(q, 10, L)
             o = oracle.search_batch(base, off, nbrs, 5, q, 10, L, m, threads=2, impl="ref")

@@ -230,7 +230,7 @@ def parse_args(argv=None):
                     help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of measure_traffic()
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-screen", action="store_true", help="switch the half-precision screening pass off (option screen = 1)")
+    ap.add_argument("--no-screen", action="store_true", help="switch the 8-bit screening pass off (option screen = 1)")
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
     ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
     ap.add_argument("--sweep", action="store_true", help="print the whole L_pq curve (CSV columns of the reference)")
@@ -580,7 +580,7 @@ def main():
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),
                    "visited": visited_desc,
-                   "screen": ("8-bit codes of the base rows (256 B per row) scored first; a neighbour is dropped there only if its exact key is "
+                   "screen": (f"8-bit codes of the base rows ({ {200: 256, 512: 528, 128: 144}.get(args.dim, 0) } B per row) scored first; a neighbour is dropped there only if its exact key is "
                               "certainly above the reject threshold; the others are scored on the f32 rows: ids, distances, hops, cmps unchanged")
                    if idx.info("last_screen") else "off",
                    "waves_per_query": idx.info("last_waves_per_query"), "register_pool": bool(idx.info("last_register_pool")),

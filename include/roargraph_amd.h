@@ -322,12 +322,14 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row
  *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on dense graphs (same measure);
  *                    results do not depend on it
- *   "screen"         0 auto | 1 off: 200-d inner-product / cosine indexes keep a second copy of the base rows in 8-bit codes
- *                    (256 bytes = two 128-byte lines per row instead of seven; made on first use) and a hop scores its
- *                    unvisited neighbours on it first; a neighbour whose exact key is CERTAINLY above the pool's reject
- *                    threshold (rigorous bound: this row's quantisation error norm x |q| + the rounding of the screen's own
- *                    arithmetic) is dropped there, the others are scored on the f32 rows as before -- ids, distances, hops
- *                    and cmps do not depend on it (csrc/roar_search_v2.h, screen8_pass)
+ *   "screen"         0 auto | 1 off | 2 on: the index keeps a second copy of the base rows in 8-bit codes (made on first use:
+ *                    200-d rows 256 bytes = two 128-byte lines instead of seven, 512-d rows 528 bytes = five lines instead of
+ *                    sixteen) and a hop scores its unvisited neighbours on it first; a neighbour whose exact key is CERTAINLY
+ *                    above the pool's reject threshold (rigorous bound: this row's quantisation error norm + the rounding of
+ *                    the screen's own arithmetic) is dropped there, the others are scored on the f32 rows as before -- ids,
+ *                    distances, hops and cmps do not depend on it (csrc/roar_search_v2.h, screen8_pass).  Kernels: inner
+ *                    product / cosine at 128, 200 and 512 floats per row, L2 at 128 and 512; auto = on for the 200-d and 512-d
+ *                    ones (at 128-d a hop gathers too little for it to pay), 2 = on wherever there is a kernel
  *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host

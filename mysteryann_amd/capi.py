@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libroargraph_amd.so")
+# (ROAR_AMD_LIB: another build of the same library, e.g. one compiled with different register budgets, for A/B measurements)
+LIB_PATH = os.environ.get("ROAR_AMD_LIB") or os.path.join(_CSRC, "libroargraph_amd.so")
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 4
 VISITED_EXACT, VISITED_LDS, VISITED_AUTO = 0, 1, 2

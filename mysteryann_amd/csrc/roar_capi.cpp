@@ -132,10 +132,10 @@ struct roar_index {
     // base rows in HBM
     float *base = nullptr;
     bool base_owned = false;
-    // 8-bit screening copy of a 200-d inner-product base set (RoarSearchParams::screen), n x 256 bytes, made on first use
+    // 8-bit screening copy of the base rows (RoarSearchParams::screen), n x roar_screen8_stride(dim) bytes, made on first use
     unsigned char *screen = nullptr;
     uint64_t screen_n = 0;
-    int screen_mode = 0;  // option "screen": 0 auto (on where the kernels have it), 1 off
+    int screen_mode = 0;  // option "screen": 0 auto (on where it pays), 1 off, 2 on wherever the kernels have it
     int launch_events = 1;  // option "launch_events": 0 = no timing events around a launch ("last_kernel_ns" then keeps its last value)
     int last_screen = 0;
     uint64_t n = 0;
@@ -488,19 +488,20 @@ int ensure_hub_rows(roar_index *idx) {
     return ROAR_OK;
 }
 
-// The screening copy (roar_search_v2.h, screen8_pass): + n x 256 bytes of HBM, one conversion pass.  Failure to make it is not an
+// The screening copy (roar_search_v2.h, screen8_pass): + n x roar_screen8_stride(dim) bytes of HBM (256 at 200-d, 528 at 512-d), one
+// conversion pass.  Failure to make it is not an
 // error: the launch then scores every neighbour on the f32 rows, as without it.
 void ensure_screen(roar_index *idx) {
     if (idx->screen && idx->screen_n == idx->n) return;
     if (idx->screen) (void)hipFree(idx->screen);
     idx->screen = nullptr;
     idx->screen_n = 0;
-    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * 256 + 256) != hipSuccess) {
+    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * roar_screen8_stride(idx->dim_pad) + 256) != hipSuccess) {
         (void)hipGetLastError();
         idx->screen = nullptr;
         return;
     }
-    int rc = roar_launch_make_screen8(idx->base, idx->ld, idx->n, idx->screen, nullptr);
+    int rc = roar_launch_make_screen8(idx->base, idx->ld, idx->dim_pad, idx->n, idx->screen, idx->ip ? 0 : 1, nullptr);
     hipError_t e = rc == 0 ? hipDeviceSynchronize() : (hipError_t)rc;
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -539,7 +540,12 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.ld = idx->ld;
     p.dim = idx->dim_pad;
     idx->last_screen = 0;
-    if (!bipartite && idx->ip && idx->dim_pad == 200 && idx->screen_mode != 1) {
+    // The kernels have the screen for 128-d and 512-d rows (both metrics) and 200-d inner product.  AUTO leaves it off at 128-d: a
+    // hop there gathers too few bytes for the second dependent round trip to pay (SIFT-1M shape, 10 000 queries, off / on:
+    // L_pq = 50 2.07 / 4.23 ms, 170 6.78 / 12.8, 500 15.5 / 31.9 ms; 512-d, WebVid-2.5M shape: 95 14.2 / 6.75, 500 69.7 / 33.1,
+    // 2 000 295 / 146 ms; 200-d, T2I-10M: 50 3.45 / 1.80, 2 000 127 / 91 ms).
+    const bool screen_kernel = idx->dim_pad == 128 || idx->dim_pad == 512 || (idx->ip && idx->dim_pad == 200);
+    if (!bipartite && screen_kernel && idx->screen_mode != 1 && (idx->screen_mode == 2 || idx->dim_pad != 128)) {
         ensure_screen(idx);
         p.screen = idx->screen;
         idx->last_screen = idx->screen ? 1 : 0;
@@ -567,7 +573,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // ("dense" is about the bytes a hop gathers -- average degree x row bytes, with 24 rows of 800 B as the line: a
     // 128-d graph of average degree 32 gathers 16 KB per hop and behaves like a sparse one: SIFT-1M shape, L_pq = 170,
     // hub form with five waves per CU 9.59 ms, plain form with eight 8.0 ms)
-    const bool dense = idx->gn && (double)idx->nedges / (double)idx->gn * (double)idx->dim_pad * 4.0 >= 24.0 * 800.0;
+    // With the screening copy a hop gathers the 8-bit rows of its neighbours and the f32 rows of the few that pass: every graph
+    // measured behaves like a sparse one (WebVid-2.5M shape, average degree 43, 10 000 queries, plain form with 4 096 tags / hub form
+    // at its best table: L_pq = 95 6.78 / 7.33 ms, 200 13.4 / 14.3, 500 33.2 / 39.7 ms).
+    const bool dense = !p.screen && idx->gn && (double)idx->nedges / (double)idx->gn * (double)idx->dim_pad * 4.0 >= 24.0 * 800.0;
     bool use_hub = false;
     if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
         int e = ensure_hub_rows(idx);
@@ -591,7 +600,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // 1 000 63.8 / 43.5 / 38.5 / 45.1, 1 400 92.9 / 73.1 / 64.2 / 61.8, 2 000 165 / 142 / 122 / 91.3 ms (scripts/quick_probe.py,
     // profiles/r03_screen_forms.txt).
     const bool screen_sparse = p.screen != nullptr && !dense && !use_hub;
-    const uint32_t lds_until = screen_sparse ? 1300u : use_hub ? 1200u : dense ? 512u : 1950u;
+    // (512-d rows, WebVid-2.5M shape: 2 048 tags / HBM tags 70.1 / 79.5 ms at L_pq = 1 000, 100.1 / 106.7 at 1 400, 175.7 / 146.1 at 2 000)
+    const uint32_t lds_until = screen_sparse ? (idx->dim_pad >= 512 ? 1600u : 1300u) : use_hub ? 1200u : dense ? 512u : 1950u;
     int mode = idx->visited_mode == ROAR_VISITED_AUTO
                    ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                    : idx->visited_mode;
@@ -635,7 +645,9 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // workgroups per CU instead of seven (SIFT-1M shape, L_pq = 170, 2 048 / 4 096 / 8 192 / 16 384 tags: 6.94 / 6.31 / 6.99 /
         // 10.03 ms with 8 184 / 7 218 / 6 645 / 6 473 scored rows per query)
         if (!use_hub && !dense && idx->dim_pad * 4u < 768u) want = 4096u;
-        if (screen_sparse) want = L < 300 ? 4096u : 2048u;
+        // (512-d: two waves per SIMD is the register limit, the 4 096-tag table costs no residency up to L_pq ~ 900:
+        // WebVid shape, 2 048 / 4 096 / 8 192 tags: L_pq = 95 7.16 / 6.78 / 7.21 ms, 200 13.9 / 13.4 / 13.9, 500 34.3 / 33.2 / 38.2 ms)
+        if (screen_sparse) want = (L < 300 || (idx->dim_pad >= 512 && L <= 900)) ? 4096u : 2048u;
         if (use_hub) want = L < 500 ? 8192u : 4096u;
         else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
@@ -729,6 +741,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         // on the T2I-10M bootstrap graph 0.305 vs 0.329 ms); one wave otherwise.  On a sparse graph a hop gathers ~50 rows
         // and the extra waves only add barriers (256 queries at L_pq = 55: 0.353 ms with one wave, 0.369 with four), and from a
         // few hundred queries on the one-wave form is ahead everywhere (1 250 queries: 0.549 vs 0.557 ms with two waves).
+        // (With the 8-bit screen `dense` is false: the extra waves share the exact scoring pass, and the screen leaves it few rows.)
         for (int w : {4, 2}) {
             if (idx->search_kernel == 2 && w != 4) continue;
             if (idx->search_kernel == 3 && w != 2) continue;
@@ -2525,7 +2538,7 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "launch_events") {
         idx->launch_events = value ? 1 : 0;
     } else if (k == "screen") {
-        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "screen must be 0 (auto) or 1 (off)");
+        if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "screen must be 0 (auto), 1 (off) or 2 (on)");
         idx->screen_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");

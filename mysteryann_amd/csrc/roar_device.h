@@ -8,8 +8,9 @@ struct RoarSearchParams {
     const float *base;
     uint64_t ld;
     uint32_t dim;
-    // SearchRoarGraph kernels, 200-d inner product only: the 8-bit screening copy of the base rows, 256 bytes per row (200 codes,
-    // scale, error bound; roar_launch_make_screen8, roar_search_v2.h screen8_pass); null = off
+    // SearchRoarGraph kernels, inner product, 200-d and 512-d rows: the 8-bit screening copy of the base rows,
+    // roar_screen8_stride(dim) bytes per row (dim codes, scale, error bound; roar_launch_make_screen8, roar_search_v2.h
+    // screen8_pass); null = off
     const unsigned char *screen;
     // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
     const uint32_t *adj;
@@ -92,6 +93,26 @@ struct RoarDistParams {
     uint32_t off_ck, off_cid, off_q, lds_bytes;
 };
 
+// Bytes per row of the screening copy: dim / 16 chunks of 16 codes, then one 16-byte chunk holding the last dim % 16 (0 or 8)
+// codes, the scale and the bound.  Rows are packed when a packed row never touches more 128-byte lines than a row padded to whole
+// lines would (512-d: 528 bytes, always five lines), padded otherwise (200-d: 208 -> 256 bytes, two lines instead of two or three).
+static inline constexpr uint32_t roar_screen8_stride(uint32_t dim) {
+    return (112u + (dim / 16u + 1u) * 16u + 127u) / 128u <= ((dim / 16u + 1u) * 16u + 127u) / 128u ? (dim / 16u + 1u) * 16u
+                                                                                                     : ((dim / 16u + 1u) * 16u + 127u) & ~127u;
+}
+// Rounding allowance of the screened sum, in units of scale x |q| (derivation: roar_search_v2.h, screen8_pass): 0.08 at 200-d
+static inline constexpr double roar_screen8_rounding(uint32_t dim) {
+    double y = (double)dim;
+    for (int i = 0; i < 40; ++i) y = 0.5 * (y + (double)dim / y);  // sqrt(dim) without <math.h>
+    return 1.25 * 383.0 * (double)dim / 16777216.0 * y * 1.0001;
+}
+// L2 form: allowance for the rounding of |x~|^2 - 2 x~.q + |q|^2 as the kernel evaluates it, in units of |x~|^2 + |q|^2
+static inline constexpr double roar_screen8_l2_rounding(uint32_t dim) {
+    double y = (double)dim;
+    for (int i = 0; i < 40; ++i) y = 0.5 * (y + (double)dim / y);
+    return 1.25 * (2.0 * dim * (1.0 + y) + dim + 8.0) / 16777216.0 * 1.0001;
+}
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -100,8 +121,10 @@ int roar_launch_search(const RoarSearchParams *p, const RoarKernelSel *sel, uint
 int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
-// f32 rows of 200 floats at stride ld -> screening rows (see RoarSearchParams::screen); out: n x 256 bytes
-int roar_launch_make_screen8(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream);
+// f32 rows of dim floats (dim % 8 == 0, dim <= 1024) at stride ld -> screening rows (see RoarSearchParams::screen);
+// out: n x roar_screen8_stride(dim) bytes
+// l2 != 0: the L2 form of the row (dim % 16 == 0): dim codes u_i with x~_i = lo + s u_i, then s, lo, |x~|^2, bound
+int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, void *stream);
 int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
 // Max resident workgroups per CU for the selected kernel at this LDS size.
 int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);

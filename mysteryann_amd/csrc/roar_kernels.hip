@@ -403,43 +403,137 @@ __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams 
     }
 }
 
-// 8-bit screening copy of 200-d rows (roar_search_v2.h, screen8_pass): one wave per row, lane l < 50 owns floats 4l .. 4l+3.
-// s = max|x| / 127, c_i = rint(x_i / s) clamped to [-127, 127], u_i = c_i + 128; e = |x - s c|_2 evaluated in f32 and rounded up;
-// bytes 200..203 = s, 204..207 = B = 1.001 e + 0.08 s.  A row with a non-finite component gets B = +inf (never screened out).
-__global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, u64 n, unsigned char *__restrict__ out) {
+// 8-bit screening copy of the base rows (roar_search_v2.h, screen8_pass): one wave per row, lane l owns floats 4l .. 4l+3 of each
+// 256-float piece.  Row out: dim codes, (dim % 16 == 0: 8 bytes of zeros,) scale, bound -- roar_screen8_stride(dim) bytes.
+__global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
+                                                                uint32_t stride, float rounding) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (v >= n) return;
-    const float *row = base + v * ld;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < 50) a = reinterpret_cast<const float4 *>(row)[lane];
-    float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fmaxf(__builtin_fabsf(a.z), __builtin_fabsf(a.w)));
-    bool bad = !(mx <= 3.0e38f);  // inf or NaN (fmaxf drops NaNs: test the components)
-    bad |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
+    const float4 *row = reinterpret_cast<const float4 *>(base + v * ld);
+    const uint32_t nf4 = dim / 4;  // <= 256
+    float4 a[4];
+    float mx = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (64 * j + lane < nf4) a[j] = row[64 * j + lane];
+        mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[j].x), __builtin_fabsf(a[j].y)),
+                                                  __builtin_fmaxf(__builtin_fabsf(a[j].z), __builtin_fabsf(a[j].w))));
+        bad |= (a[j].x != a[j].x) | (a[j].y != a[j].y) | (a[j].z != a[j].z) | (a[j].w != a[j].w);  // (fmaxf drops NaNs: test the components)
+    }
+    bad |= !(mx <= 3.0e38f);  // inf
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-    const bool anybad = __ballot(bad) != 0;
+    const bool anybad = __ballot(bad) != 0 || (mx > 0.f && mx < 1.0e-30f);  // (a scale near the subnormals: no bound is claimed)
     const float sc = mx / 127.0f;
     const float inv = mx > 0.f ? 127.0f / mx : 0.f;
-    const float f[4] = {a.x, a.y, a.z, a.w};
-    uint32_t word = 0;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * stride);
     float e2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float c = __builtin_rintf(f[i] * inv);
-        c = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, c));
-        const float d = f[i] - sc * c;
-        e2 = __builtin_fmaf(d, d, e2);
-        word |= (uint32_t)((int)c + 128) << (8 * i);
+    for (int j = 0; j < 4; ++j) {
+        const float f[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float c = __builtin_rintf(f[i] * inv);
+            c = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, c));
+            const float d = (f[i] - sc * c) * inv;  // in units of s: the square of a tiny d itself would underflow
+            e2 = __builtin_fmaf(d, d, e2);          // (lanes past the row hold zeros: c = 0, d = 0)
+            word |= (uint32_t)((int)c + 128) << (8 * i);
+        }
+        if (64 * j + lane < nf4) o32[64 * j + lane] = anybad ? 0x80808080u : word;
     }
-    if (lane >= 50) e2 = 0.f;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * 256);
-    if (lane < 50) o32[lane] = anybad ? 0x80808080u : word;
-    if (lane == 50) o32[50] = __float_as_uint(anybad ? 0.f : sc);
-    if (lane == 51) o32[51] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * __builtin_sqrtf(e2) * 1.0001f + 0.08f * sc);
-    if (lane >= 52) o32[lane] = 0u;
+    const uint32_t meta = (dim / 16u) * 4u + 2u;  // the last two words of the chunk after the full ones
+    if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
+    if (lane == 1) o32[meta + 1] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + rounding * sc);
+    for (uint32_t w = nf4 + lane; w < stride / 4; w += 64)  // zeros between the codes and the two floats, and after them
+        if (w != meta && w != meta + 1) o32[w] = 0u;
+}
+
+// The L2 form (screen8_pass, !IP): x~_i = lo + s u_i with u_i in 0..255, lo = the row's minimum and s = (max - min) / 255 -- or the
+// power of two at or above that if the row is then coded without error (rows of small integers: SIFT).  Row out: dim codes (dim % 16
+// == 0), s, lo, |x~|^2, B with B >= |x - x~| + the distance between the x~ the kernel means (lo + s u in real arithmetic) and the
+// rounded one measured here.
+__global__ void __launch_bounds__(256) roar_make_screen8_l2_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
+                                                                   uint32_t stride) {
+    const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const float4 *row = reinterpret_cast<const float4 *>(base + v * ld);
+    const uint32_t nf4 = dim / 4;  // <= 256
+    float f[16];
+    float mx = -3.0e38f, mn = 3.0e38f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = 64 * j + lane < nf4;
+        const float4 a = in ? row[64 * j + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        f[4 * j] = a.x, f[4 * j + 1] = a.y, f[4 * j + 2] = a.z, f[4 * j + 3] = a.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = f[4 * j + i];
+            bad |= in && (x != x || !(__builtin_fabsf(x) <= 1.0e17f));  // NaN, inf, or so large that |x~|^2 may overflow
+            if (in) mx = __builtin_fmaxf(mx, x), mn = __builtin_fminf(mn, x);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = __builtin_fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    bool anybad = __ballot(bad) != 0;
+    anybad |= !anybad && mx - mn > 0.f && mx - mn < 1.0e-30f;  // (a scale near the subnormals: no bound is claimed)
+    const float range = anybad ? 0.f : mx - mn, lo = anybad ? 0.f : mn;
+    const float tight = range / 255.0f;
+    uint32_t words[4];
+    float sc = 0.f, e2 = 0.f, n2 = 0.f;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 0) {  // the power of two at or above the tight scale
+            int ex;
+            const float mant = __builtin_frexpf(tight, &ex);  // tight = mant 2^ex, mant in [0.5, 1)
+            sc = tight > 0.f ? __builtin_ldexpf(1.0f, mant == 0.5f ? ex - 1 : ex) : 0.f;
+        } else {
+            sc = tight;
+        }
+        const float inv = sc > 0.f ? 1.0f / sc : 0.f;
+        e2 = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            words[j] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = 64 * j + lane < nf4;
+                float c = __builtin_rintf((f[4 * j + i] - lo) * inv);
+                c = __builtin_fminf(255.f, __builtin_fmaxf(0.f, c));
+                const float xh = in ? __builtin_fmaf(sc, c, lo) : 0.f;
+                const float d = in ? (f[4 * j + i] - xh) * inv : 0.f;  // in units of s (sc = 0: a constant row, x~ = x)
+                e2 = __builtin_fmaf(d, d, e2);
+                n2 = __builtin_fmaf(xh, xh, n2);
+                words[j] |= (uint32_t)(int)c << (8 * i);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            e2 += __shfl_xor(e2, o, 64);
+            n2 += __shfl_xor(n2, o, 64);
+        }
+        if (e2 == 0.f) break;  // (uniform: e2 is the same in every lane)
+    }
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (64 * j + lane < nf4) o32[64 * j + lane] = anybad ? 0u : words[j];
+    const uint32_t meta = (dim / 16u) * 4u;
+    if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
+    if (lane == 1) o32[meta + 1] = __float_as_uint(lo);
+    if (lane == 2) o32[meta + 2] = __float_as_uint(anybad ? 0.f : n2);
+    if (lane == 3)
+        o32[meta + 3] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 2.5e-7f * __builtin_sqrtf(n2) * 1.0001f);
+    for (uint32_t w = meta + 4 + lane; w < stride / 4; w += 64) o32[w] = 0u;
 }
 
 // local ids of a shard -> global ids (index-sharded configuration); "no result" stays "no result"
@@ -631,9 +725,16 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
     return (int)hipGetLastError();
 }
 
-extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint64_t n, unsigned char *out, void *stream) {
+extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, void *stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, (u64)n, out);
+    if (dim % 8 || dim > 1024 || (l2 && dim % 16)) return (int)hipErrorInvalidValue;
+    if (l2) {
+        hipLaunchKernelGGL(roar_make_screen8_l2_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
+                           roar_screen8_stride(dim));
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
+                       roar_screen8_stride(dim), (float)roar_screen8_rounding(dim));
     return (int)hipGetLastError();
 }
 

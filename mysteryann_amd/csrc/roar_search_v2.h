@@ -281,14 +281,16 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
     }
 }
 
-// ---- 8-bit screening in front of the exact scoring (200-d inner-product shape) -----------------------------------------------
+// ---- 8-bit screening in front of the exact scoring (inner product; 200-d and 512-d rows) -------------------------------------
 // What a hop costs the memory system is counted in 128-byte line requests, and of the ~49 rows a hop scores
 // only ~6 have a key under the pool's reject threshold.  The index therefore keeps a second copy of the base rows in 8-bit
-// codes -- 256 bytes = TWO lines per row instead of seven -- and a hop first scores its unvisited neighbours on that copy.
-// Row: bytes 0..199 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then s = max|x| / 127 (f32) and B (f32).
+// codes -- at 200-d 256 bytes = TWO lines per row instead of seven, at 512-d 528 bytes = five lines instead of sixteen -- and a
+// hop first scores its unvisited neighbours on that copy.
+// Row: bytes 0..D-1 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then s = max|x| / 127 (f32) and B (f32).
 // With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2, the quantisation error of THIS row, evaluated when the copy is made.
-// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.065 s |q|
-// (gamma_200 (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(200) |q|).  B = 1.001 e + 0.08 s, hence
+// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.065 s |q| at D = 200
+// (gamma_D (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(D) |q|).  B = 1.001 e + c(D) s with
+// c(D) = 1.25 * 383 D 2^-24 sqrt(D) (roar_screen8_rounding: 0.08 at 200, 0.33 at 512), hence
 //     exact distance of the row  >=  -(screened dot) - |q| B,
 // and a neighbour is dropped here only if that lower bound is above the distance of the pool's last entry, i.e. only if its
 // exact key is certainly above the reject threshold -- which the merge would have rejected (neighbor.h:151-153).  Everything
@@ -296,8 +298,6 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
 // neighbours BEFORE the screen, as the reference counts its distance evaluations.  (The threshold is read before the hop's
 // merges: it can only be looser than the reference's.  A row of zeros has s = 0, B = 0: its screened value is exact.  A row with a
 // component that is not finite has B = +inf and is never dropped.)
-constexpr uint32_t SCREEN8_STRIDE = 256;
-
 __device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, float acc) {
     const float4 q0 = *reinterpret_cast<const float4 *>(lq16), q1 = *reinterpret_cast<const float4 *>(lq16 + 4),
                  q2 = *reinterpret_cast<const float4 *>(lq16 + 8), q3 = *reinterpret_cast<const float4 *>(lq16 + 12);
@@ -320,11 +320,16 @@ __device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, floa
     return acc;
 }
 
-template <int RR>
+// D = padded row length: D / 16 full chunks of 16 codes, lane t of a row's group takes chunks t, t + 4, ...; the chunk after them holds
+// the last D % 16 (0 or 8) codes, s and B.
+template <int D, bool IP, int RR>
 __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
-                                             float thr_d, float qnorm, float qsum128, uint32_t &w, int t, int g) {
+                                             float thr_d, float qa, float qb, uint32_t &w, int t, int g) {
+    constexpr int NDC = D / 16, NJ = NDC / 4, REM = D % 16;
+    static_assert(NDC % 4 == 0 && (REM == 0 || (IP && REM == 8)), "screening copy: row lengths of 64 k (or, inner product, 64 k + 8) floats");
+    constexpr uint32_t STRIDE = roar_screen8_stride(D);
     uint32_t id[RR];
-    uint4 x[RR][4];
+    uint4 x[RR][NJ + 1];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const uint32_t c = p0 + 16 * r + g;
@@ -332,10 +337,10 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
-        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * SCREEN8_STRIDE);
+        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) x[r][j] = row[t + 4 * j];  // chunks t, t + 4, t + 8 (16 codes each)
-        x[r][3] = row[12];                                      // codes 192..199, s, B (used by lane 0)
+        for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
+        x[r][NJ] = row[NDC];  // the last codes (used by lane 0), s, B
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
@@ -344,13 +349,13 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
     for (int r = 0; r < RR; ++r) {
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             acc = dot16_u8(x[r][j], lq + 16 * (t + 4 * j), acc);
             __builtin_amdgcn_sched_barrier(0);  // (one chunk's query fragments at a time: hoisting them all costs registers)
         }
-        {  // the last 8 codes: lane 0 only (the other lanes add zeros)
-            const uint4 v = x[r][3];
-            const float4 qa = *reinterpret_cast<const float4 *>(lq + 192), qb = *reinterpret_cast<const float4 *>(lq + 196);
+        if constexpr (REM == 8) {  // the last 8 codes: lane 0 only (the other lanes add zeros)
+            const uint4 v = x[r][NJ];
+            const float4 qa = *reinterpret_cast<const float4 *>(lq + 16 * NDC), qb = *reinterpret_cast<const float4 *>(lq + 16 * NDC + 4);
             float a2 = 0.f;
             a2 = __builtin_fmaf((float)(v.x & 0xFFu), qa.x, a2);
             a2 = __builtin_fmaf((float)((v.x >> 8) & 0xFFu), qa.y, a2);
@@ -364,8 +369,18 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
         }
         acc += quad_xor1(acc);
         acc += quad_xor2(acc);
-        const float sc = __uint_as_float(x[r][3].z), bnd = __uint_as_float(x[r][3].w);
-        const float lower = -(sc * (acc - qsum128)) - qnorm * bnd;  // the exact distance is >= lower
+        float lower;  // the exact distance is >= lower
+        if constexpr (IP) {  // qa = |q| rounded up, qb = 128 sum q_i
+            const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(x[r][NJ].w);
+            lower = -(sc * (acc - qb)) - qa * bnd - 1.0e-36f;  // (1e-36: what products lost to underflow can amount to)
+        } else {  // qa = |q|^2, qb = sum q_i; row: s, lo, |x~|^2, B
+            const float sc = __uint_as_float(x[r][NJ].x), lo = __uint_as_float(x[r][NJ].y), n2 = __uint_as_float(x[r][NJ].z),
+                        bnd = __uint_as_float(x[r][NJ].w);
+            const float xq = __builtin_fmaf(lo, qb, sc * acc);
+            const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-36f;
+            const float tt = __builtin_sqrtf(__builtin_fmaxf(dlo, 0.f)) * 0.999999f - bnd;
+            lower = tt > 0.f ? tt * tt * 0.99999f : 0.f;
+        }
         const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
         bm[r] = __ballot(keep);
     }
@@ -377,13 +392,18 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
     wave_sync();
 }
 
+template <int D, bool IP>
 __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
-                                                 float qnorm, float qsum128, int lane) {
+                                                 float qa, float qb, int lane) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
-    // (four rows per lane group and pass -- a whole hop in one round trip -- do not fit the registers beside the hop's state)
-    for (; p0 + 16 < m; p0 += 32) screen8_pass<2>(scr, lq, cid, p0, m, thr_d, qnorm, qsum128, w, t, g);
-    for (; p0 < m; p0 += 16) screen8_pass<1>(scr, lq, cid, p0, m, thr_d, qnorm, qsum128, w, t, g);
+    // (200-d: four rows per lane group and pass -- a whole hop in one round trip -- do not fit the registers beside the hop's state;
+    //  512-d: a row is nine 16-byte registers per lane, one row per group and pass like the exact scoring of that shape)
+    if constexpr (D <= 128 && !IP)  // (the inner-product kernel of that length spills with four rows per group)
+        for (; p0 + 48 < m; p0 += 64) screen8_pass<D, IP, 4>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+    if constexpr (D <= 256)
+        for (; p0 + 16 < m; p0 += 32) screen8_pass<D, IP, 2>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+    for (; p0 < m; p0 += 16) screen8_pass<D, IP, 1>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
     return w;
 }
 
@@ -399,6 +419,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
+    // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
+    constexpr int SD = (NCH == 8 && !TAIL) ? 128 : (NCH == 32 && !TAIL) ? 512 : (IP && NCH == 12 && TAIL) ? 200 : 0;
     // (a build with R = 1 and four waves per SIMD for launches with the screen on -- sixteen workgroups per CU -- spills inside
     // the hop and is 60 % slower: 2.94 against 1.83 ms at L_pq = 50; dropped)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -500,8 +522,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         }
         block_sync();
 
-        // |q| rounded up and 128 * sum q_i (screen8_pass): kept in LDS (ctrl[8], ctrl[9]), not in registers through the hop
-        if constexpr (IP && NCH == 12 && TAIL) {
+        // |q| rounded up and 128 * sum q_i (L2: |q|^2 and sum q_i; screen8_pass): kept in LDS (ctrl[8], ctrl[9]), not in registers through the hop
+        if constexpr (SD > 0) {
             if (wid == 0) {
                 float qnorm, qsum128;
                 float s2 = 0.f, s1 = 0.f;
@@ -514,8 +536,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     s2 += __shfl_xor(s2, o, 64);
                     s1 += __shfl_xor(s1, o, 64);
                 }
-                qnorm = __builtin_sqrtf(s2) * 1.0001f;
-                qsum128 = 128.f * s1;
+                qnorm = IP ? __builtin_sqrtf(s2) * 1.0001f : s2;  // (L2: |q|^2 and sum q_i)
+                qsum128 = IP ? 128.f * s1 : s1;
                 if (lane == 0) {
                     ctrl[8] = __float_as_uint(qnorm);
                     ctrl[9] = __float_as_uint(qsum128);
@@ -705,7 +727,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         a2 = nrow[128 + lane];
                         if (HUB) a3 = nrow[192 + lane];
                     }
-                    if constexpr (IP && NCH == 12 && TAIL) {  // half-precision screen (see screen_pass), once the pool is full
+                    if constexpr (SD > 0) {  // 8-bit screen (see screen8_pass), once the pool is full
                         if (psize == L && m > 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
                             const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -716,7 +738,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             if (scr) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
-                                m = screen8_rows(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), lane);
+                                m = screen8_rows<SD, IP>(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), lane);
                             }
                         }
                     }
@@ -861,8 +883,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
 // Register budget: three waves per SIMD (the explicit maximum keeps the scheduler from trading the batched loads of
 // a scoring pass for an occupancy the LDS footprint does not allow anyway).
+// (512-d rows: two waves per SIMD -- a row is 32 registers per lane in the exact pass, nine in the screen; at three per SIMD both
+// spill inside the hop: WebVid-2.5M shape, L_pq = 95, 10 000 queries, screen on, 7.79 ms at three, 6.75 ms at two)
+#ifndef ROAR_WPE_512
+#define ROAR_WPE_512 2
+#endif
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(NCH > 16 ? ROAR_WPE_512 : 3, NCH > 16 ? ROAR_WPE_512 : 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
     search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED>(p);
 }

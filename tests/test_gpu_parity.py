@@ -699,8 +699,12 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
             if mode == 0:
                 assert np.array_equal(r["cmps"], o["cmps"]), (kernel, L)
     idx.set_option("search_kernel", 0)
+    idx.set_option("screen", 1)
     idx.SearchRoarGraphBatch(q, K, 50)
     assert idx.info("last_waves_per_query") == 4  # at most one query per CU on a dense graph: the four-wave form
+    idx.set_option("screen", 0)
+    idx.SearchRoarGraphBatch(q, K, 50)
+    assert idx.info("last_waves_per_query") == 1  # (with the 8-bit screen few rows are left to score: one wave)
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
@@ -992,17 +996,20 @@ def test_device_builder_matches_the_survey_probe_of_the_compiled_reference(golde
     idx.close()
 
 
+@pytest.mark.parametrize("shape", ["ip-200", "ip-512", "ip-128", "l2-128", "l2-512"])
 @pytest.mark.parametrize("mode", [0, 1, 3], ids=["exact", "lds", "forgetful"])
-def test_screening_pass_never_changes_a_result(mode, built_lib):
-    """The 8-bit screening copy (200-d inner product; option "screen") may only drop neighbours whose exact key is certainly
-    above the reject threshold: ids, distances, hops and cmps with it equal those without it and the CPU oracle's -- on
-    rows chosen to strain the bound: a wide dynamic range inside a row (one component 1e4 times the others: the codes of
-    the others are all zero), rows of zeros, duplicated rows (exact ties), tiny rows, rows scaled by 1e-20 / 1e+15, a zero
-    query, a query with one dominant component."""
+def test_screening_pass_never_changes_a_result(mode, shape, built_lib):
+    """The 8-bit screening copy (inner product: 128-, 200- and 512-d rows; L2: 128- and 512-d rows; option "screen") may only drop
+    neighbours whose exact key is certainly above the reject threshold: ids, distances, hops and cmps with it equal those without it
+    and the CPU oracle's -- on rows chosen to strain the bound: a wide dynamic range inside a row (one component 1e4 times the
+    others: the codes of the others are all zero), rows of zeros, duplicated rows (exact ties), tiny rows, rows scaled by 1e-20 /
+    1e+15, rows of small integers (coded without error), constant rows, a zero query, a query with one dominant component, queries
+    that are base rows plus a little noise (L2: the three terms of the screened distance cancel)."""
     import oracle
     from mysteryann_amd import index as mi
 
-    n, d, nq = 6000, 200, 40
+    ip, d = shape.startswith("ip"), int(shape.split("-")[1])
+    n, nq = 6000, 40
     rng = np.random.default_rng(123)
     base = rng.standard_normal((n, d)).astype(np.float32)
     base[100:400, 7] *= 1e4                      # one dominant component
@@ -1011,28 +1018,41 @@ def test_screening_pass_never_changes_a_result(mode, built_lib):
     base[700:900] *= np.float32(1e-20)
     base[900:1100] *= np.float32(1e15)
     base[1100:1300] = np.float32(1e-42)          # subnormal components
+    base[1300:2300] = np.minimum(np.abs(np.rint(base[1300:2300] * 40)), 255)  # SIFT-like small integers
+    base[2300:2320] = np.float32(3.25)           # constant rows
+    base[2320:2400] += np.float32(100.0)         # a large common offset
     q = rng.standard_normal((nq, d)).astype(np.float32)
     q[0] = 0.0
     q[1] = 0.0
     q[1, 7] = 3.0
     q[2] *= np.float32(1e-10)
     q[3] *= np.float32(1e10)
+    q[4:12] = base[1300:1308] + rng.standard_normal((8, d)).astype(np.float32) * np.float32(0.5)
+    q[12:16] = base[2320:2324] + rng.standard_normal((4, d)).astype(np.float32) * np.float32(1e-3)
+    q[16:20] = np.minimum(np.abs(np.rint(q[16:20] * 40)), 255)
     deg = rng.integers(20, 70, n)
     off = np.zeros(n + 1, np.uint64)
     off[1:] = np.cumsum(deg)
     nbrs = rng.integers(0, n, int(off[-1])).astype(np.uint32)
-    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
+    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT if ip else mi.L2, None)
     idx.SetBaseData(base)
     idx.SetProjectionGraph(5, off, nbrs)
     idx.set_option("visited_mode", mode)
+    if mode == 3:  # (the plan picks table size and hub bitmap by what a hop gathers: the same form with and without the screen)
+        idx.set_option("vis_entries", 4096)
+        idx.set_option("hub_mode", 1)
     for L in (10, 50, 64, 65, 300):
-        o = oracle.search_batch(base, off, nbrs, 5, q, K, L, 1)
+        o = oracle.search_batch(base, off, nbrs, 5, q, K, L, 1 if ip else 0)
         idx.set_option("screen", 1)
         a = idx.SearchRoarGraphBatch(q, K, L)
         assert idx.info("last_screen") == 0
-        idx.set_option("screen", 0)
+        idx.set_option("screen", 2)
         b = idx.SearchRoarGraphBatch(q, K, L)
         assert idx.info("last_screen") == 1
+        idx.set_option("screen", 0)
+        c = idx.SearchRoarGraphBatch(q, K, L)
+        assert idx.info("last_screen") == (0 if d == 128 else 1)  # auto: not at 128-d, where it does not pay
+        assert np.array_equal(c["ids"], o["ids"])
         for key in ("ids", "dists", "hops") + (("cmps",) if mode != 3 else ()):
             assert np.array_equal(a[key], o[key]), (L, key, "screen off")
             assert np.array_equal(b[key], o[key]), (L, key, "screen on")

@@ -673,6 +673,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     off += bp_wg ? 4 * 64 * 8 : 4 * 192;
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
+    if (p.screen) off += round_up(idx->dim_pad, 16);  // the query's 8-bit codes (screen8i_pass)
     p.off_vis = off;
     off += 2 * entries;
     p.off_ctrl = off;

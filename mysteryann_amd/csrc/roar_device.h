@@ -8,9 +8,10 @@ struct RoarSearchParams {
     const float *base;
     uint64_t ld;
     uint32_t dim;
-    // SearchRoarGraph kernels, inner product, 200-d and 512-d rows: the 8-bit screening copy of the base rows,
-    // roar_screen8_stride(dim) bytes per row (dim codes, scale, error bound; roar_launch_make_screen8, roar_search_v2.h
-    // screen8_pass); null = off
+    // SearchRoarGraph kernels, 128-d / 200-d (inner product) / 512-d rows: the 8-bit screening copy of the base rows,
+    // roar_screen8_stride(dim) bytes per row (dim codes, scale, bounds; roar_launch_make_screen8, roar_search_v2.h
+    // screen8i_pass / screen8_pass); null = off.  With it the LDS block at off_q holds the query's own 8-bit codes (dim
+    // bytes) behind its dim floats
     const unsigned char *screen;
     // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
     const uint32_t *adj;
@@ -99,12 +100,6 @@ struct RoarDistParams {
 static inline constexpr uint32_t roar_screen8_stride(uint32_t dim) {
     return (112u + (dim / 16u + 1u) * 16u + 127u) / 128u <= ((dim / 16u + 1u) * 16u + 127u) / 128u ? (dim / 16u + 1u) * 16u
                                                                                                      : ((dim / 16u + 1u) * 16u + 127u) & ~127u;
-}
-// Rounding allowance of the screened sum, in units of scale x |q| (derivation: roar_search_v2.h, screen8_pass): 0.08 at 200-d
-static inline constexpr double roar_screen8_rounding(uint32_t dim) {
-    double y = (double)dim;
-    for (int i = 0; i < 40; ++i) y = 0.5 * (y + (double)dim / y);  // sqrt(dim) without <math.h>
-    return 1.25 * 383.0 * (double)dim / 16777216.0 * y * 1.0001;
 }
 // L2 form: allowance for the rounding of |x~|^2 - 2 x~.q + |q|^2 as the kernel evaluates it, in units of |x~|^2 + |q|^2
 static inline constexpr double roar_screen8_l2_rounding(uint32_t dim) {

@@ -403,10 +403,17 @@ __global__ void __launch_bounds__(64) roar_distance_kernel(const RoarDistParams 
     }
 }
 
-// 8-bit screening copy of the base rows (roar_search_v2.h, screen8_pass): one wave per row, lane l owns floats 4l .. 4l+3 of each
-// 256-float piece.  Row out: dim codes, (dim % 16 == 0: 8 bytes of zeros,) scale, bound -- roar_screen8_stride(dim) bytes.
+// 8-bit screening copy of the base rows, inner-product form (roar_search_v2.h, screen8i_pass): one wave per row, lane l owns floats
+// 4l .. 4l+3 of each 256-float piece.  Row out: dim codes c_i in [-127, 127] (two's complement), (dim % 16 == 0: 8 bytes of zeros,)
+// s = max|x| / 127, then one word = B rounded up to bf16 (low half) | N rounded up to bf16 (high half), B >= |x - s c|_2, N >= |s c|_2
+// -- roar_screen8_stride(dim) bytes.
+__device__ __forceinline__ uint32_t bf16_up(float v) {  // v >= 0 or +inf: the smallest bf16 >= v, as the high half of an f32
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0xFFFFu) ? (b >> 16) + 1u : (b >> 16);  // (+inf and values whose low half is zero stay; the largest finite rounds to +inf)
+}
+
 __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
-                                                                uint32_t stride, float rounding) {
+                                                                uint32_t stride) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (v >= n) return;
@@ -423,14 +430,14 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
                                                   __builtin_fmaxf(__builtin_fabsf(a[j].z), __builtin_fabsf(a[j].w))));
         bad |= (a[j].x != a[j].x) | (a[j].y != a[j].y) | (a[j].z != a[j].z) | (a[j].w != a[j].w);  // (fmaxf drops NaNs: test the components)
     }
-    bad |= !(mx <= 3.0e38f);  // inf
+    bad |= !(mx <= 1.0e30f);  // inf, or so large that the bounds may overflow
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
     const bool anybad = __ballot(bad) != 0 || (mx > 0.f && mx < 1.0e-30f);  // (a scale near the subnormals: no bound is claimed)
     const float sc = mx / 127.0f;
     const float inv = mx > 0.f ? 127.0f / mx : 0.f;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(out + v * stride);
-    float e2 = 0.f;
+    float e2 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float f[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
@@ -441,16 +448,24 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
             c = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, c));
             const float d = (f[i] - sc * c) * inv;  // in units of s: the square of a tiny d itself would underflow
             e2 = __builtin_fmaf(d, d, e2);          // (lanes past the row hold zeros: c = 0, d = 0)
-            word |= (uint32_t)((int)c + 128) << (8 * i);
+            c2 = __builtin_fmaf(c, c, c2);          // (integers, the sum stays below 2^24: exact)
+            word |= ((uint32_t)(int)c & 0xFFu) << (8 * i);
         }
-        if (64 * j + lane < nf4) o32[64 * j + lane] = anybad ? 0x80808080u : word;
+        if (64 * j + lane < nf4) o32[64 * j + lane] = anybad ? 0u : word;
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+    for (int o = 32; o >= 1; o >>= 1) {
+        e2 += __shfl_xor(e2, o, 64);
+        c2 += __shfl_xor(c2, o, 64);
+    }
     const uint32_t meta = (dim / 16u) * 4u + 2u;  // the last two words of the chunk after the full ones
+    // N: |s c| rounded up.  B: |x - s c| rounded up (1.001: the f32 evaluation of e2), + 2^-23 N: each d_i was measured against the ROUNDED
+    // product s c_i, the kernel means the real one
+    const float nrm = sc * __builtin_sqrtf(c2) * 1.0001f;
+    const float bnd = 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 1.2e-7f * nrm;
     if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
-    if (lane == 1) o32[meta + 1] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + rounding * sc);
-    for (uint32_t w = nf4 + lane; w < stride / 4; w += 64)  // zeros between the codes and the two floats, and after them
+    if (lane == 1) o32[meta + 1] = anybad ? 0x7F80u : (bf16_up(bnd) | (bf16_up(nrm) << 16));
+    for (uint32_t w = nf4 + lane; w < stride / 4; w += 64)  // zeros between the codes and the meta words, and after them
         if (w != meta && w != meta + 1) o32[w] = 0u;
 }
 
@@ -734,7 +749,7 @@ extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
-                       roar_screen8_stride(dim), (float)roar_screen8_rounding(dim));
+                       roar_screen8_stride(dim));
     return (int)hipGetLastError();
 }
 

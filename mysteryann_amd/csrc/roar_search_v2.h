@@ -281,23 +281,34 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
     }
 }
 
-// ---- 8-bit screening in front of the exact scoring (inner product; 200-d and 512-d rows) -------------------------------------
+// ---- 8-bit screening in front of the exact scoring ----------------------------------------------------------------------------
 // What a hop costs the memory system is counted in 128-byte line requests, and of the ~49 rows a hop scores
 // only ~6 have a key under the pool's reject threshold.  The index therefore keeps a second copy of the base rows in 8-bit
 // codes -- at 200-d 256 bytes = TWO lines per row instead of seven, at 512-d 528 bytes = five lines instead of sixteen -- and a
-// hop first scores its unvisited neighbours on that copy.
-// Row: bytes 0..D-1 = u_i = c_i + 128 with c_i = rint(x_i * 127 / max|x|) in [-127, 127], then s = max|x| / 127 (f32) and B (f32).
-// With x~ = s c:  |q.x - q.x~| <= |q| e,  e = |x - s c|_2, the quantisation error of THIS row, evaluated when the copy is made.
-// The kernel evaluates s (sum q_i u_i - 128 sum q_i) in f32; the rounding of that expression is below 0.065 s |q| at D = 200
-// (gamma_D (255 + 128) |q|_1 s plus the last operations, with |q|_1 <= sqrt(D) |q|).  B = 1.001 e + c(D) s with
-// c(D) = 1.25 * 383 D 2^-24 sqrt(D) (roar_screen8_rounding: 0.08 at 200, 0.33 at 512), hence
-//     exact distance of the row  >=  -(screened dot) - |q| B,
-// and a neighbour is dropped here only if that lower bound is above the distance of the pool's last entry, i.e. only if its
-// exact key is certainly above the reject threshold -- which the merge would have rejected (neighbor.h:151-153).  Everything
-// else goes on to the exact pass, whose distances, keys and merges are the reference's, bit for bit.  cmps counts the
-// neighbours BEFORE the screen, as the reference counts its distance evaluations.  (The threshold is read before the hop's
-// merges: it can only be looser than the reference's.  A row of zeros has s = 0, B = 0: its screened value is exact.  A row with a
-// component that is not finite has B = +inf and is never dropped.)
+// hop first scores its unvisited neighbours on that copy, dropping a neighbour there only if its exact key is CERTAINLY above
+// the reject threshold -- which the merge would have rejected (neighbor.h:151-153).  Everything else goes on to the exact pass,
+// whose distances, keys and merges are the reference's, bit for bit.  cmps counts the neighbours BEFORE the screen, as the
+// reference counts its distance evaluations.  (The threshold is read before the hop's merges: it can only be looser than the
+// reference's.)
+//
+// Inner product (screen8i_pass): BOTH sides in 8 bits, the sum in integers.
+//   row:   bytes 0..D-1 = c_i = rint(x_i * 127 / max|x|) in [-127, 127] (two's complement), then s = max|x| / 127 (f32) and two
+//          bounds rounded UP to bf16 in one word: B >= |x - s c|_2 (this row's quantisation error, evaluated when the copy is made)
+//          and N >= |s c|_2.  With x~ = s c:  x.q = x~.q~ + x~.(q - q~) + (x - x~).q.
+//   query: once per query, q~ = t k with k_i = rint(q_i * 127 / max|q|), t = max|q| / 127, E >= |q - q~|_2 + 2^-22 |q| (the second
+//          term pays for the three roundings of s t I below), |q| rounded up; k packed behind the f32 query in LDS.
+//   hop:   I = sum c_i k_i with v_dot4_i32_i8 -- exact, |I| <= D 127^2 < 2^24 for D <= 1024 -- and
+//              exact distance of the row  >=  -(s t I) - (E N + |q| B) - 1e-36     (1e-36: products lost to underflow)
+//          sixteen codes per instruction quartet instead of sixteen conversions and sixteen FMAs: the launch is bound by instruction
+//          issue and by dependent round trips, not by bytes (SQ counters), and 200 bytes of row per 4-lane group leave
+//          room for FOUR rows per group and pass -- a whole hop's neighbours in one round trip.
+//   A row of zeros has s = 0, B = N = 0: its screened value is exact.  A row with a component that is not finite, or with a scale
+//   near the subnormals, has B = +inf and is never dropped; a query like that switches the screen off for itself (|q| = +inf).
+//
+// L2 (screen8_pass): the query stays in f32.
+//   row:   u_i in 0..255 with x~_i = lo + s u_i, then s, lo, |x~|^2 and B >= |x - x~| (roar_make_screen8_l2_kernel);
+//   hop:   D^ = |x~|^2 - 2 (lo sum q_i + s sum q_i u_i) + |q|^2 in f32, less kappa(D) (|x~|^2 + |q|^2) for the rounding of that
+//          expression (the three terms may cancel); exact distance >= (sqrt(D^) - B)^2 when sqrt(D^) > B, else 0.
 __device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, float acc) {
     const float4 q0 = *reinterpret_cast<const float4 *>(lq16), q1 = *reinterpret_cast<const float4 *>(lq16 + 4),
                  q2 = *reinterpret_cast<const float4 *>(lq16 + 8), q3 = *reinterpret_cast<const float4 *>(lq16 + 12);
@@ -320,13 +331,20 @@ __device__ __forceinline__ float dot16_u8(const uint4 v, const float *lq16, floa
     return acc;
 }
 
-// D = padded row length: D / 16 full chunks of 16 codes, lane t of a row's group takes chunks t, t + 4, ...; the chunk after them holds
-// the last D % 16 (0 or 8) codes, s and B.
-template <int D, bool IP, int RR>
-__device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
-                                             float thr_d, float qa, float qb, uint32_t &w, int t, int g) {
+__device__ __forceinline__ int quad_sum_i32(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // lane ^ 2
+    return v;
+}
+
+// Inner product.  D = padded row length: D / 16 full chunks of 16 codes, lane t of a row's group takes chunks t, t + 4, ...; the
+// chunk after them holds the last D % 16 (0 or 8) codes (lane 0's), s and the two bounds.  lk = the query's codes in LDS.
+// qa = |q| rounded up, qb = t, qc = E.
+template <int D, int RR>
+__device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ scr, const uint32_t *lk, uint32_t *cid, uint32_t p0, uint32_t m,
+                                              float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g) {
     constexpr int NDC = D / 16, NJ = NDC / 4, REM = D % 16;
-    static_assert(NDC % 4 == 0 && (REM == 0 || (IP && REM == 8)), "screening copy: row lengths of 64 k (or, inner product, 64 k + 8) floats");
+    static_assert(NDC % 4 == 0 && (REM == 0 || REM == 8), "screening copy: row lengths of 64 k or 64 k + 8 floats");
     constexpr uint32_t STRIDE = roar_screen8_stride(D);
     uint32_t id[RR];
     uint4 x[RR][NJ + 1];
@@ -340,7 +358,70 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
         const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
-        x[r][NJ] = row[NDC];  // the last codes (used by lane 0), s, B
+        x[r][NJ] = row[NDC];
+    }
+    wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
+    int acc[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) acc[r] = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {  // one chunk of the query's codes serves the RR rows
+        const uint4 k = *reinterpret_cast<const uint4 *>(lk + 4 * (t + 4 * j));
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            acc[r] = __builtin_amdgcn_sdot4((int)x[r][j].x, (int)k.x, acc[r], false);
+            acc[r] = __builtin_amdgcn_sdot4((int)x[r][j].y, (int)k.y, acc[r], false);
+            acc[r] = __builtin_amdgcn_sdot4((int)x[r][j].z, (int)k.z, acc[r], false);
+            acc[r] = __builtin_amdgcn_sdot4((int)x[r][j].w, (int)k.w, acc[r], false);
+        }
+    }
+    if constexpr (REM == 8) {  // the last 8 codes: lane 0 of the group only
+        const uint2 k = *reinterpret_cast<const uint2 *>(lk + 4 * NDC);
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            int a2 = __builtin_amdgcn_sdot4((int)x[r][NJ].x, (int)k.x, 0, false);
+            a2 = __builtin_amdgcn_sdot4((int)x[r][NJ].y, (int)k.y, a2, false);
+            acc[r] += (t == 0) ? a2 : 0;
+        }
+    }
+    u64 bm[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const int I = quad_sum_i32(acc[r]);
+        const uint32_t bn = x[r][NJ].w;
+        const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(bn << 16), nrm = __uint_as_float(bn & 0xFFFF0000u);
+        const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-36f;  // the exact distance is >= lower
+        const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
+        bm[r] = __ballot(keep);
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
+        w += (uint32_t)__popcll(bm[r]);
+    }
+    wave_sync();
+}
+
+// L2.  Row: D codes (D % 16 == 0), then s, lo, |x~|^2, B.  qa = |q|^2, qb = sum q_i.
+template <int D, int RR>
+__device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
+                                             float thr_d, float qa, float qb, uint32_t &w, int t, int g) {
+    constexpr int NDC = D / 16, NJ = NDC / 4;
+    static_assert(NDC % 4 == 0 && D % 16 == 0, "screening copy, L2: row lengths of 64 k floats");
+    constexpr uint32_t STRIDE = roar_screen8_stride(D);
+    uint32_t id[RR];
+    uint4 x[RR][NJ + 1];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint32_t c = p0 + 16 * r + g;
+        id[r] = cid[c < m ? c : m - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
+        x[r][NJ] = row[NDC];
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
@@ -353,34 +434,14 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
             acc = dot16_u8(x[r][j], lq + 16 * (t + 4 * j), acc);
             __builtin_amdgcn_sched_barrier(0);  // (one chunk's query fragments at a time: hoisting them all costs registers)
         }
-        if constexpr (REM == 8) {  // the last 8 codes: lane 0 only (the other lanes add zeros)
-            const uint4 v = x[r][NJ];
-            const float4 qa = *reinterpret_cast<const float4 *>(lq + 16 * NDC), qb = *reinterpret_cast<const float4 *>(lq + 16 * NDC + 4);
-            float a2 = 0.f;
-            a2 = __builtin_fmaf((float)(v.x & 0xFFu), qa.x, a2);
-            a2 = __builtin_fmaf((float)((v.x >> 8) & 0xFFu), qa.y, a2);
-            a2 = __builtin_fmaf((float)((v.x >> 16) & 0xFFu), qa.z, a2);
-            a2 = __builtin_fmaf((float)(v.x >> 24), qa.w, a2);
-            a2 = __builtin_fmaf((float)(v.y & 0xFFu), qb.x, a2);
-            a2 = __builtin_fmaf((float)((v.y >> 8) & 0xFFu), qb.y, a2);
-            a2 = __builtin_fmaf((float)((v.y >> 16) & 0xFFu), qb.z, a2);
-            a2 = __builtin_fmaf((float)(v.y >> 24), qb.w, a2);
-            acc += (t == 0) ? a2 : 0.f;
-        }
         acc += quad_xor1(acc);
         acc += quad_xor2(acc);
-        float lower;  // the exact distance is >= lower
-        if constexpr (IP) {  // qa = |q| rounded up, qb = 128 sum q_i
-            const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(x[r][NJ].w);
-            lower = -(sc * (acc - qb)) - qa * bnd - 1.0e-36f;  // (1e-36: what products lost to underflow can amount to)
-        } else {  // qa = |q|^2, qb = sum q_i; row: s, lo, |x~|^2, B
-            const float sc = __uint_as_float(x[r][NJ].x), lo = __uint_as_float(x[r][NJ].y), n2 = __uint_as_float(x[r][NJ].z),
-                        bnd = __uint_as_float(x[r][NJ].w);
-            const float xq = __builtin_fmaf(lo, qb, sc * acc);
-            const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-36f;
-            const float tt = __builtin_sqrtf(__builtin_fmaxf(dlo, 0.f)) * 0.999999f - bnd;
-            lower = tt > 0.f ? tt * tt * 0.99999f : 0.f;
-        }
+        const float sc = __uint_as_float(x[r][NJ].x), lo = __uint_as_float(x[r][NJ].y), n2 = __uint_as_float(x[r][NJ].z),
+                    bnd = __uint_as_float(x[r][NJ].w);
+        const float xq = __builtin_fmaf(lo, qb, sc * acc);
+        const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-36f;
+        const float tt = __builtin_sqrtf(__builtin_fmaxf(dlo, 0.f)) * 0.999999f - bnd;
+        const float lower = tt > 0.f ? tt * tt * 0.99999f : 0.f;  // the exact distance is >= lower
         const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
         bm[r] = __ballot(keep);
     }
@@ -392,18 +453,27 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
     wave_sync();
 }
 
+// lq = the f32 query in LDS, its 8-bit codes (inner product) behind it
 template <int D, bool IP>
 __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
-                                                 float qa, float qb, int lane) {
+                                                 float qa, float qb, float qc, int lane) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
-    // (200-d: four rows per lane group and pass -- a whole hop in one round trip -- do not fit the registers beside the hop's state;
-    //  512-d: a row is nine 16-byte registers per lane, one row per group and pass like the exact scoring of that shape)
-    if constexpr (D <= 128 && !IP)  // (the inner-product kernel of that length spills with four rows per group)
-        for (; p0 + 48 < m; p0 += 64) screen8_pass<D, IP, 4>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
-    if constexpr (D <= 256)
-        for (; p0 + 16 < m; p0 += 32) screen8_pass<D, IP, 2>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
-    for (; p0 < m; p0 += 16) screen8_pass<D, IP, 1>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+    if constexpr (IP) {
+        const uint32_t *lk = reinterpret_cast<const uint32_t *>(lq + ((D + 3) & ~3));
+        // rows per group and pass: four up to 256 codes (64 bytes of row per lane), two at 512 (72 bytes)
+        constexpr int RB = D <= 256 ? 4 : 2;
+        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
+        if constexpr (RB == 4)
+            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
+        for (; p0 < m; p0 += 16) screen8i_pass<D, 1>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
+    } else {
+        if constexpr (D <= 128)
+            for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+        if constexpr (D <= 256)
+            for (; p0 + 16 < m; p0 += 32) screen8_pass<D, 2>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+        for (; p0 < m; p0 += 16) screen8_pass<D, 1>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+    }
     return w;
 }
 
@@ -522,25 +592,65 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         }
         block_sync();
 
-        // |q| rounded up and 128 * sum q_i (L2: |q|^2 and sum q_i; screen8_pass): kept in LDS (ctrl[8], ctrl[9]), not in registers through the hop
+        // the query's side of the screen (screen8i_pass / screen8_pass), kept in LDS (ctrl[8..10]), not in registers through the hop:
+        // inner product: |q| rounded up, t, E and the codes k behind the f32 query; L2: |q|^2 and sum q_i
         if constexpr (SD > 0) {
-            if (wid == 0) {
-                float qnorm, qsum128;
-                float s2 = 0.f, s1 = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const bool screen_on = *const_cast<const unsigned char *const volatile *>(
+                                       &((const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr())->screen) != nullptr;
+#else
+            const bool screen_on = false;
+#endif
+            if (wid == 0 && screen_on) {  // (the LDS behind the query is there for the codes only when the launch has a screening copy)
+                float s2 = 0.f, s1 = 0.f, mx = 0.f;
                 for (uint32_t i = lane; i < p.dim; i += 64) {
                     s2 = __builtin_fmaf(lq[i], lq[i], s2);
                     s1 += lq[i];
+                    mx = __builtin_fmaxf(mx, __builtin_fabsf(lq[i]));
                 }
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) {
                     s2 += __shfl_xor(s2, o, 64);
                     s1 += __shfl_xor(s1, o, 64);
+                    mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
                 }
-                qnorm = IP ? __builtin_sqrtf(s2) * 1.0001f : s2;  // (L2: |q|^2 and sum q_i)
-                qsum128 = IP ? 128.f * s1 : s1;
+                float qa, qb, qc = 0.f;
+                if constexpr (IP) {
+                    const float tq = mx / 127.0f, inv = mx > 0.f ? 127.0f / mx : 0.f;
+                    uint32_t *lk = reinterpret_cast<uint32_t *>(lq + ((SD + 3) & ~3));
+                    float e2 = 0.f;
+                    for (uint32_t i = lane; i < SD / 4; i += 64) {  // four codes per lane and step
+                        const float4 v = *reinterpret_cast<const float4 *>(lq + 4 * i);
+                        const float f[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float k = __builtin_rintf(f[c] * inv);
+                            k = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, k));
+                            const float d = (f[c] - tq * k) * inv;  // in units of t (the square of a tiny d would underflow)
+                            e2 = __builtin_fmaf(d, d, e2);
+                            word |= ((uint32_t)(int)k & 0xFFu) << (8 * c);
+                        }
+                        lk[i] = word;
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+                    qa = __builtin_sqrtf(s2) * 1.0001f;
+                    qb = tq;
+                    // |q - t k| rounded up, + 4e-7 |q| for the roundings of t k_i inside d, of s t I and of the last sums, + what the
+                    // EXACT pass's own f32 sum (16 partial sums of D / 16 products, then the tree: distance.h:179-223) can differ from
+                    // the real-number inner product by -- the bound has to hold for the distance as the reference computes it
+                    qc = 1.001f * tq * __builtin_sqrtf(e2) + (4.0e-7f + 1.25f * (float)(SD / 16 + 6) * 5.9604645e-8f) * qa;
+                    // no bound is claimed for a query that is not finite, whose squares overflow or whose scale is near the subnormals
+                    if (!(mx <= 1.0e18f) || !(s2 <= 3.0e38f) || (mx > 0.f && mx < 1.0e-30f)) qa = __builtin_inff();
+                } else {
+                    qa = s2;
+                    qb = s1;
+                }
                 if (lane == 0) {
-                    ctrl[8] = __float_as_uint(qnorm);
-                    ctrl[9] = __float_as_uint(qsum128);
+                    ctrl[8] = __float_as_uint(qa);
+                    ctrl[9] = __float_as_uint(qb);
+                    ctrl[10] = __float_as_uint(qc);
                 }
                 wave_sync();
             }
@@ -738,7 +848,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             if (scr) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
-                                m = screen8_rows<SD, IP>(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), lane);
+                                m = screen8_rows<SD, IP>(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]),
+                                                         __uint_as_float(ctrl[10]), lane);
                             }
                         }
                     }

@@ -359,6 +359,15 @@ int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
  * fallback, and leaves no device memory behind. */
 int roar_debug_fail_device_alloc_at(int64_t n);
 
+/* Known-answer surface for the 8-bit screen (csrc/roar_search_v2.h, screen8i_pass / screen8_pass; no reference counterpart -- the
+ * screen is this library's own device): runs the search kernels' screening passes over explicit pairs, row ids[q][c] of query q
+ * against its OWN threshold thresholds[q][c], and returns keeps[q][c] = 1 if the screen would pass the row on to the exact scoring,
+ * 0 if it would drop it.  The property the search relies on: with thresholds[q][c] = the row's exact distance (roar_distances),
+ * every verdict is 1 -- a row is only ever dropped when its exact distance is certainly ABOVE the threshold.  Host arrays,
+ * [nq][m]; shapes with a screening kernel only (option "screen"); makes the screening copy if the index has none yet. */
+int roar_debug_screen_keeps(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, const uint32_t *ids,
+                            const float *thresholds, uint32_t m, uint8_t *keeps);
+
 /* Known-answer surface for NeighborPriorityQueue (include/efanna2e/neighbor.h:138-223): replays a scripted sequence on
  * the device with the queue routines of the search kernels -- ops[i] == 0: insert(ids[i], dists[i]) (:150-183), else
  * closest_unexpanded() if has_unexpanded_node() (:185-194) -- and returns the state after every op,

@@ -29,7 +29,7 @@ SYMBOLS = [
     "roar_host_alloc", "roar_host_free", "roar_queue_trace", "roar_build_roargraph_device",
     "roar_rebase_ids_device", "roar_sharded_create", "roar_sharded_destroy", "roar_sharded_shard",
     "roar_sharded_set_id_base", "roar_search_batch_sharded", "roar_sharded_info", "roar_host_register",
-    "roar_host_unregister", "roar_debug_fail_device_alloc_at",
+    "roar_host_unregister", "roar_debug_fail_device_alloc_at", "roar_debug_screen_keeps",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
     l.roar_search_bipartite_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     l.roar_debug_fail_device_alloc_at.argtypes = [C.c_int64]
+    l.roar_debug_screen_keeps.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, fp, C.c_uint32, C.POINTER(C.c_uint8)]
     l.roar_host_register.argtypes = [vp, C.c_uint64]
     l.roar_host_unregister.argtypes = [vp]
     l.roar_rebase_ids_device.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]

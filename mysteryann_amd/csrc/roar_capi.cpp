@@ -2336,6 +2336,58 @@ int roar_distances(roar_index *idx, const float *queries, uint64_t nq, uint32_t 
     return ROAR_OK;
 }
 
+int roar_debug_screen_keeps(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, const uint32_t *ids,
+                            const float *thresholds, uint32_t m, uint8_t *keeps) {
+    DeviceRestore keep_device_;
+    if (!idx || !queries || !ids || !thresholds || !keeps) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (!idx->base) return fail(ROAR_ERR_ARG, "screen check before base vectors were loaded");
+    if (nq == 0 || m == 0) return ROAR_OK;
+    if (qstride_floats < idx->dim) return fail(ROAR_ERR_ARG, "query stride smaller than the dimension");
+    if (!(idx->dim_pad == 128 || idx->dim_pad == 512 || (idx->ip && idx->dim_pad == 200)))
+        return fail(ROAR_ERR_ARG, "no screening kernel for rows of %u floats with this metric", idx->dim_pad);
+    for (uint64_t i = 0; i < nq * m; ++i)
+        if (ids[i] >= idx->n) return fail(ROAR_ERR_ARG, "id %u outside the base set", ids[i]);
+    std::lock_guard<std::mutex> guard(idx->mu);
+    int e = use_device(idx);
+    if (e) return e;
+    ensure_screen(idx);
+    if (!idx->screen) return fail(ROAR_ERR_DEVICE, "the screening copy could not be made");
+    float *q_dev = nullptr, *c_dev = nullptr;
+    uint32_t *i_dev = nullptr;
+    std::vector<float> buf;
+    try {
+        buf.assign((size_t)nq * idx->dim_pad, 0.0f);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory");
+    }
+    for (uint64_t i = 0; i < nq; ++i)
+        memcpy(buf.data() + i * idx->dim_pad, queries + i * qstride_floats, idx->dim * sizeof(float));
+    struct Free {  // every exit below releases the three device blocks
+        float *&q, *&c;
+        uint32_t *&i;
+        ~Free() { (void)hipFree(q), (void)hipFree(c), (void)hipFree(i); }
+    } free_all{q_dev, c_dev, i_dev};
+    HIP_TRY(roar_dev_malloc((void **)&q_dev, buf.size() * sizeof(float)));
+    HIP_TRY(roar_dev_malloc((void **)&i_dev, (size_t)nq * m * 4));
+    HIP_TRY(roar_dev_malloc((void **)&c_dev, (size_t)nq * m * 4));
+    HIP_TRY(hipMemcpy(q_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(i_dev, ids, (size_t)nq * m * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c_dev, thresholds, (size_t)nq * m * 4, hipMemcpyHostToDevice));
+    int rc = idx->ip ? roar_launch_screen_check_1(idx->screen, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, nullptr)
+                     : roar_launch_screen_check_0(idx->screen, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, nullptr);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "screen check launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> verdict;
+    try {
+        verdict.resize((size_t)nq * m);
+    } catch (...) {
+        return fail(ROAR_ERR_DEVICE, "out of host memory");
+    }
+    HIP_TRY(hipMemcpy(verdict.data(), c_dev, (size_t)nq * m * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < verdict.size(); ++i) keeps[i] = verdict[i] != 0.0f ? 1 : 0;
+    return ROAR_OK;
+}
+
 int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
                           uint32_t *ids_dev, float *dists_dev, void *hip_stream) {
     DeviceRestore keep_device_;

@@ -340,9 +340,11 @@ __device__ __forceinline__ int quad_sum_i32(int v) {
 // Inner product.  D = padded row length: D / 16 full chunks of 16 codes, lane t of a row's group takes chunks t, t + 4, ...; the
 // chunk after them holds the last D % 16 (0 or 8) codes (lane 0's), s and the two bounds.  lk = the query's codes in LDS.
 // qa = |q| rounded up, qb = t, qc = E.
-template <int D, int RR>
+// CHECK (roar_screen_check_kernel, tests): row c is tested against its OWN threshold chk[c] and the verdict goes to chk[c] (1.0 = kept)
+// instead of the compaction.
+template <int D, int RR, bool CHECK = false>
 __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ scr, const uint32_t *lk, uint32_t *cid, uint32_t p0, uint32_t m,
-                                              float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g) {
+                                              float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g, float *chk = nullptr) {
     constexpr int NDC = D / 16, NJ = NDC / 4, REM = D % 16;
     static_assert(NDC % 4 == 0 && (REM == 0 || REM == 8), "screening copy: row lengths of 64 k or 64 k + 8 floats");
     constexpr uint32_t STRIDE = roar_screen8_stride(D);
@@ -391,21 +393,31 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
         const uint32_t bn = x[r][NJ].w;
         const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(bn << 16), nrm = __uint_as_float(bn & 0xFFFF0000u);
         const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-36f;  // the exact distance is >= lower
-        const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
+        const uint32_t c = p0 + 16 * r + g;
+        float th = thr_d;
+        if constexpr (CHECK) th = chk[c < m ? c : m - 1];
+        const bool keep = t == 0 && c < m && !(lower > th);
         bm[r] = __ballot(keep);
     }
+    if constexpr (CHECK) {
+        wave_sync();
 #pragma unroll
-    for (int r = 0; r < RR; ++r) {
-        if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
-        w += (uint32_t)__popcll(bm[r]);
+        for (int r = 0; r < RR; ++r)
+            if (t == 0 && p0 + 16 * r + g < m) chk[p0 + 16 * r + g] = ((bm[r] >> (4 * g)) & 1ull) ? 1.0f : 0.0f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
+            w += (uint32_t)__popcll(bm[r]);
+        }
     }
     wave_sync();
 }
 
 // L2.  Row: D codes (D % 16 == 0), then s, lo, |x~|^2, B.  qa = |q|^2, qb = sum q_i.
-template <int D, int RR>
+template <int D, int RR, bool CHECK = false>
 __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
-                                             float thr_d, float qa, float qb, uint32_t &w, int t, int g) {
+                                             float thr_d, float qa, float qb, uint32_t &w, int t, int g, float *chk = nullptr) {
     constexpr int NDC = D / 16, NJ = NDC / 4;
     static_assert(NDC % 4 == 0 && D % 16 == 0, "screening copy, L2: row lengths of 64 k floats");
     constexpr uint32_t STRIDE = roar_screen8_stride(D);
@@ -442,39 +454,100 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
         const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-36f;
         const float tt = __builtin_sqrtf(__builtin_fmaxf(dlo, 0.f)) * 0.999999f - bnd;
         const float lower = tt > 0.f ? tt * tt * 0.99999f : 0.f;  // the exact distance is >= lower
-        const bool keep = t == 0 && p0 + 16 * r + g < m && !(lower > thr_d);
+        const uint32_t c = p0 + 16 * r + g;
+        float th = thr_d;
+        if constexpr (CHECK) th = chk[c < m ? c : m - 1];
+        const bool keep = t == 0 && c < m && !(lower > th);
         bm[r] = __ballot(keep);
     }
+    if constexpr (CHECK) {
+        wave_sync();
 #pragma unroll
-    for (int r = 0; r < RR; ++r) {
-        if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
-        w += (uint32_t)__popcll(bm[r]);
+        for (int r = 0; r < RR; ++r)
+            if (t == 0 && p0 + 16 * r + g < m) chk[p0 + 16 * r + g] = ((bm[r] >> (4 * g)) & 1ull) ? 1.0f : 0.0f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if ((bm[r] >> (4 * g + t)) & 1ull) cid[w + lanes_below(bm[r])] = id[r];
+            w += (uint32_t)__popcll(bm[r]);
+        }
     }
     wave_sync();
 }
 
 // lq = the f32 query in LDS, its 8-bit codes (inner product) behind it
-template <int D, bool IP>
+template <int D, bool IP, bool CHECK = false>
 __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
-                                                 float qa, float qb, float qc, int lane) {
+                                                 float qa, float qb, float qc, int lane, float *chk = nullptr) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
     if constexpr (IP) {
         const uint32_t *lk = reinterpret_cast<const uint32_t *>(lq + ((D + 3) & ~3));
         // rows per group and pass: four up to 256 codes (64 bytes of row per lane), two at 512 (72 bytes)
         constexpr int RB = D <= 256 ? 4 : 2;
-        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
+        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
         if constexpr (RB == 4)
-            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
-        for (; p0 < m; p0 += 16) screen8i_pass<D, 1>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g);
+            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+        for (; p0 < m; p0 += 16) screen8i_pass<D, 1, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
     } else {
         if constexpr (D <= 128)
-            for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+            for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
         if constexpr (D <= 256)
-            for (; p0 + 16 < m; p0 += 32) screen8_pass<D, 2>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
-        for (; p0 < m; p0 += 16) screen8_pass<D, 1>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g);
+            for (; p0 + 16 < m; p0 += 32) screen8_pass<D, 2, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
+        for (; p0 < m; p0 += 16) screen8_pass<D, 1, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
     }
     return w;
+}
+
+// The query's side of the screen, one wave: inner product: qa = |q| rounded up, qb = t, qc = E and the codes k behind the f32 query in
+// LDS; L2: qa = |q|^2, qb = sum q_i.
+template <int SD, bool IP>
+__device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane, float &qa, float &qb, float &qc) {
+    float s2 = 0.f, s1 = 0.f, mx = 0.f;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        s2 = __builtin_fmaf(lq[i], lq[i], s2);
+        s1 += lq[i];
+        mx = __builtin_fmaxf(mx, __builtin_fabsf(lq[i]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s2 += __shfl_xor(s2, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    qc = 0.f;
+    if constexpr (IP) {
+        const float tq = mx / 127.0f, inv = mx > 0.f ? 127.0f / mx : 0.f;
+        uint32_t *lk = reinterpret_cast<uint32_t *>(lq + ((SD + 3) & ~3));
+        float e2 = 0.f;
+        for (uint32_t i = lane; i < SD / 4; i += 64) {  // four codes per lane and step
+            const float4 v = *reinterpret_cast<const float4 *>(lq + 4 * i);
+            const float f[4] = {v.x, v.y, v.z, v.w};
+            uint32_t word = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float k = __builtin_rintf(f[c] * inv);
+                k = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, k));
+                const float d = (f[c] - tq * k) * inv;  // in units of t (the square of a tiny d would underflow)
+                e2 = __builtin_fmaf(d, d, e2);
+                word |= ((uint32_t)(int)k & 0xFFu) << (8 * c);
+            }
+            lk[i] = word;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+        qa = __builtin_sqrtf(s2) * 1.0001f;
+        qb = tq;
+        // |q - t k| rounded up, + 4e-7 |q| for the roundings of t k_i inside d, of s t I and of the last sums, + what the
+        // EXACT pass's own f32 sum (16 partial sums of D / 16 products, then the tree: distance.h:179-223) can differ from
+        // the real-number inner product by -- the bound has to hold for the distance as the reference computes it
+        qc = 1.001f * tq * __builtin_sqrtf(e2) + (4.0e-7f + 1.25f * (float)(SD / 16 + 6) * 5.9604645e-8f) * qa;
+        // no bound is claimed for a query that is not finite, whose squares overflow or whose scale is near the subnormals
+        if (!(mx <= 1.0e18f) || !(s2 <= 3.0e38f) || (mx > 0.f && mx < 1.0e-30f)) qa = __builtin_inff();
+    } else {
+        qa = s2;
+        qb = s1;
+    }
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue, which would
@@ -602,51 +675,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             const bool screen_on = false;
 #endif
             if (wid == 0 && screen_on) {  // (the LDS behind the query is there for the codes only when the launch has a screening copy)
-                float s2 = 0.f, s1 = 0.f, mx = 0.f;
-                for (uint32_t i = lane; i < p.dim; i += 64) {
-                    s2 = __builtin_fmaf(lq[i], lq[i], s2);
-                    s1 += lq[i];
-                    mx = __builtin_fmaxf(mx, __builtin_fabsf(lq[i]));
-                }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    s2 += __shfl_xor(s2, o, 64);
-                    s1 += __shfl_xor(s1, o, 64);
-                    mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-                }
-                float qa, qb, qc = 0.f;
-                if constexpr (IP) {
-                    const float tq = mx / 127.0f, inv = mx > 0.f ? 127.0f / mx : 0.f;
-                    uint32_t *lk = reinterpret_cast<uint32_t *>(lq + ((SD + 3) & ~3));
-                    float e2 = 0.f;
-                    for (uint32_t i = lane; i < SD / 4; i += 64) {  // four codes per lane and step
-                        const float4 v = *reinterpret_cast<const float4 *>(lq + 4 * i);
-                        const float f[4] = {v.x, v.y, v.z, v.w};
-                        uint32_t word = 0;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float k = __builtin_rintf(f[c] * inv);
-                            k = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, k));
-                            const float d = (f[c] - tq * k) * inv;  // in units of t (the square of a tiny d would underflow)
-                            e2 = __builtin_fmaf(d, d, e2);
-                            word |= ((uint32_t)(int)k & 0xFFu) << (8 * c);
-                        }
-                        lk[i] = word;
-                    }
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 64);
-                    qa = __builtin_sqrtf(s2) * 1.0001f;
-                    qb = tq;
-                    // |q - t k| rounded up, + 4e-7 |q| for the roundings of t k_i inside d, of s t I and of the last sums, + what the
-                    // EXACT pass's own f32 sum (16 partial sums of D / 16 products, then the tree: distance.h:179-223) can differ from
-                    // the real-number inner product by -- the bound has to hold for the distance as the reference computes it
-                    qc = 1.001f * tq * __builtin_sqrtf(e2) + (4.0e-7f + 1.25f * (float)(SD / 16 + 6) * 5.9604645e-8f) * qa;
-                    // no bound is claimed for a query that is not finite, whose squares overflow or whose scale is near the subnormals
-                    if (!(mx <= 1.0e18f) || !(s2 <= 3.0e38f) || (mx > 0.f && mx < 1.0e-30f)) qa = __builtin_inff();
-                } else {
-                    qa = s2;
-                    qb = s1;
-                }
+                float qa, qb, qc;
+                screen8_query<SD, IP>(lq, p.dim, lane, qa, qb, qc);
                 if (lane == 0) {
                     ctrl[8] = __float_as_uint(qa);
                     ctrl[9] = __float_as_uint(qb);
@@ -1063,6 +1093,46 @@ const void *pick_form(const RoarKernelSel &s) {
 }
 
 }  // namespace
+
+#if ROAR_TU_MODE == 1
+// Known-answer surface for the screen (roar_debug_screen_keeps, tests): workgroup (q, b) runs the search's own screening passes over
+// rows ids[q][64 b .. 64 b + 64) of query q, each row against its OWN threshold chk[q][c]; chk[q][c] becomes 1.0 (kept) or 0.0.
+template <bool IP, int D>
+__global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned char *__restrict__ scr, const float *__restrict__ queries, u64 qstride,
+                                                               const uint32_t *__restrict__ ids, float *chk, uint32_t m) {
+    __shared__ __align__(16) float lq[D + D / 4 + 4];
+    __shared__ uint32_t cid[64];
+    __shared__ float th[64];
+    const int lane = threadIdx.x;
+    const u64 q = blockIdx.x;
+    const uint32_t b0 = blockIdx.y * 64u, mm = (m - b0 < 64u) ? m - b0 : 64u;
+    for (int i = lane; i < D; i += 64) lq[i] = queries[q * qstride + i];
+    cid[lane] = (uint32_t)lane < mm ? ids[q * m + b0 + lane] : 0u;
+    th[lane] = (uint32_t)lane < mm ? chk[q * m + b0 + lane] : 0.f;
+    wave_sync();
+    float qa, qb, qc;
+    screen8_query<D, IP>(lq, D, lane, qa, qb, qc);
+    wave_sync();
+    (void)screen8_rows<D, IP, true>(scr, lq, cid, mm, 0.f, qa, qb, qc, lane, th);
+    wave_sync();
+    if ((uint32_t)lane < mm) chk[q * m + b0 + lane] = th[lane];
+}
+
+#define ROAR_CHECK_NAME2(i) roar_launch_screen_check_##i
+#define ROAR_CHECK_NAME(i) ROAR_CHECK_NAME2(i)
+extern "C" int ROAR_CHECK_NAME(ROAR_TU_IP)(const unsigned char *scr, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
+                                           const uint32_t *ids, float *chk, uint32_t m, void *stream) {
+    constexpr bool IP = ROAR_TU_IP != 0;
+    if (nq == 0 || m == 0) return 0;
+    const dim3 grid((uint32_t)nq, (m + 63u) / 64u);
+    if (dim == 128) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 128>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
+    else if (dim == 512) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 512>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
+    else if (dim == 200 && IP) {
+        if constexpr (IP) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 200>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
+    } else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+#endif
 
 // One of these per translation unit (visited mode x metric): kernel address for a selection, or null.
 #define ROAR_PICK_NAME2(m, i) roar_pick_search_##m##_##i

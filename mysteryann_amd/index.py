@@ -380,6 +380,20 @@ class IndexBipartite:
                                             capi.u32p(ids), ids.shape[1], capi.f32p(out)))
         return out
 
+    def ScreenKeeps(self, queries, ids, thresholds):
+        """roar_debug_screen_keeps: would the 8-bit screen pass row ids[q][c] of query q on to the exact scoring when the pool's
+        reject threshold is thresholds[q][c]?  -> uint8 [nq, m]."""
+        import ctypes as C
+
+        queries = np.ascontiguousarray(queries, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        thresholds = np.ascontiguousarray(thresholds, np.float32)
+        assert thresholds.shape == ids.shape
+        out = np.zeros(ids.shape, np.uint8)
+        capi.check(self._lib.roar_debug_screen_keeps(self._h, capi.f32p(queries), queries.shape[0], queries.shape[1], capi.u32p(ids),
+                                                     capi.f32p(thresholds), ids.shape[1], out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
 
 class ShardedIndex:
     """The index-sharded configuration (roar_sharded_*): shard s is an IndexBipartite over its own

@@ -1060,6 +1060,68 @@ def test_screening_pass_never_changes_a_result(mode, shape, built_lib):
     idx.close()
 
 
+@pytest.mark.parametrize("shape", ["ip-200", "ip-512", "ip-128", "l2-128", "l2-512"])
+def test_screen_never_drops_a_row_at_or_under_the_threshold(shape, built_lib):
+    """The property the search relies on, pair by pair (roar_debug_screen_keeps runs the kernels' own screening passes): with the
+    threshold set to a row's EXACT distance as the reference computes it (roar_distances: bit-equal to distance.h), the screen must
+    keep the row -- for every one of ~1 M (query, row) pairs per shape, ordinary and adversarial (wide dynamic range inside a row,
+    zero / constant / integer / tiny / huge / subnormal rows, rows with a common offset, zero and one-component queries, tiny and
+    huge queries, queries that are base rows plus noise).  And it is not vacuous: with the threshold a few per cent of |q||x| under
+    the exact distance, ordinary rows are dropped."""
+    from mysteryann_amd import index as mi
+
+    ip, d = shape.startswith("ip"), int(shape.split("-")[1])
+    n, nq, m = 8192, 256, 4096
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base[100:400, 7] *= 1e4
+    base[400:420] = 0.0
+    base[500:600] = base[600:700]
+    base[700:900] *= np.float32(1e-20)
+    base[900:1100] *= np.float32(1e15)
+    base[1100:1300] = np.float32(1e-42)
+    base[1300:2300] = np.minimum(np.abs(np.rint(base[1300:2300] * 40)), 255)
+    base[2300:2320] = np.float32(3.25)
+    base[2320:2400] += np.float32(100.0)
+    base[2400:2600] *= np.float32(1e-12)
+    base[2600:2700] = np.float32(1e-25) * rng.standard_normal((100, d)).astype(np.float32)
+    base[2700:2800, ::2] = 0.0
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = 0.0
+    q[1] = 0.0
+    q[1, 7] = 3.0
+    q[2] *= np.float32(1e-10)
+    q[3] *= np.float32(1e10)
+    q[4:12] = base[1300:1308] + rng.standard_normal((8, d)).astype(np.float32) * np.float32(0.5)
+    q[12:16] = base[2320:2324] + rng.standard_normal((4, d)).astype(np.float32) * np.float32(1e-3)
+    q[16:20] = np.minimum(np.abs(np.rint(q[16:20] * 40)), 255)
+    q[20:24] *= np.float32(1e-20)
+    q[24:28] = base[4000:4004]                       # a query that IS a base row
+    q[28:32] = -base[4000:4004]
+    q[32:36, 1:] *= np.float32(1e-6)                  # one dominant component
+    ids = np.stack([rng.permutation(n)[:m] for _ in range(nq)]).astype(np.uint32)
+    ids[:, :2800:7] = np.arange(0, 2800, 7, dtype=np.uint32)  # the special rows are in every query's list
+    idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT if ip else mi.L2, None)
+    idx.SetBaseData(base)
+    exact = idx.Distances(q, ids)
+    keep = idx.ScreenKeeps(q, ids, exact)
+    bad = np.argwhere(keep == 0)
+    assert bad.size == 0, (shape, "dropped at threshold = exact distance", bad[:5], [(int(ids[a, b]), float(exact[a, b])) for a, b in bad[:5]])
+    # just above the exact distance the verdict must stay "keep" as well (the threshold only got looser)
+    up = np.nextafter(exact, np.float32(np.inf))
+    assert idx.ScreenKeeps(q, ids, up).all()
+    # not vacuous: ordinary queries x ordinary rows, threshold 5 % of |q||x| under the exact distance -> dropped
+    oq = np.arange(40, nq)
+    ordinary = ids[oq] >= 4100
+    qn = np.linalg.norm(q[oq].astype(np.float64), axis=1)[:, None]
+    xn = np.linalg.norm(base.astype(np.float64), axis=1)[ids[oq]]
+    margin = (0.05 * qn * xn) if ip else (0.1 * qn * xn + 0.0)
+    low = (exact[oq].astype(np.float64) - margin).astype(np.float32)
+    k2 = idx.ScreenKeeps(q[oq], ids[oq], low)
+    assert k2[ordinary].mean() < 0.02, (shape, float(k2[ordinary].mean()))
+    idx.close()
+
+
 def test_device_builder_refuses_lists_that_name_no_base_point(built_lib):
     """roar_build_roargraph_device reads the learn->base lists from the caller's HBM: an id outside the base set must be
     refused like the host form refuses it ("learn base knn file error"), not read or written out of bounds; a float tensor

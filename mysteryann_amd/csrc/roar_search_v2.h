@@ -298,7 +298,7 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
 //   query: once per query, q~ = t k with k_i = rint(q_i * 127 / max|q|), t = max|q| / 127, E >= |q - q~|_2 + 2^-22 |q| (the second
 //          term pays for the three roundings of s t I below), |q| rounded up; k packed behind the f32 query in LDS.
 //   hop:   I = sum c_i k_i with v_dot4_i32_i8 -- exact, |I| <= D 127^2 < 2^24 for D <= 1024 -- and
-//              exact distance of the row  >=  -(s t I) - (E N + |q| B) - 1e-36     (1e-36: products lost to underflow)
+//              exact distance of the row  >=  -(s t I) - (E N + |q| B) - 1e-30     (1e-30: products lost to underflow, also if subnormals were flushed)
 //          sixteen codes per instruction quartet instead of sixteen conversions and sixteen FMAs: the launch is bound by instruction
 //          issue and by dependent round trips, not by bytes (SQ counters), and 200 bytes of row per 4-lane group leave
 //          room for FOUR rows per group and pass -- a whole hop's neighbours in one round trip.
@@ -392,7 +392,7 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
         const int I = quad_sum_i32(acc[r]);
         const uint32_t bn = x[r][NJ].w;
         const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(bn << 16), nrm = __uint_as_float(bn & 0xFFFF0000u);
-        const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-36f;  // the exact distance is >= lower
+        const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-30f;  // the exact distance is >= lower
         const uint32_t c = p0 + 16 * r + g;
         float th = thr_d;
         if constexpr (CHECK) th = chk[c < m ? c : m - 1];
@@ -451,7 +451,7 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
         const float sc = __uint_as_float(x[r][NJ].x), lo = __uint_as_float(x[r][NJ].y), n2 = __uint_as_float(x[r][NJ].z),
                     bnd = __uint_as_float(x[r][NJ].w);
         const float xq = __builtin_fmaf(lo, qb, sc * acc);
-        const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-36f;
+        const float dlo = (n2 - 2.f * xq + qa) - (float)roar_screen8_l2_rounding(D) * (n2 + qa) - 1.0e-30f;
         const float tt = __builtin_sqrtf(__builtin_fmaxf(dlo, 0.f)) * 0.999999f - bnd;
         const float lower = tt > 0.f ? tt * tt * 0.99999f : 0.f;  // the exact distance is >= lower
         const uint32_t c = p0 + 16 * r + g;

@@ -564,8 +564,9 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
     constexpr int SD = (NCH == 8 && !TAIL) ? 128 : (NCH == 32 && !TAIL) ? 512 : (IP && NCH == 12 && TAIL) ? 200 : 0;
-    // (a build with R = 1 and four waves per SIMD for launches with the screen on -- sixteen workgroups per CU -- spills inside
-    // the hop and is 60 % slower: 2.94 against 1.83 ms at L_pq = 50; dropped)
+    // (a build with R = 1 and four waves per SIMD for launches with the screen on -- sixteen workgroups per CU: with the screen's f32
+    // form it spilled inside the hop, 2.94 against 1.83 ms at L_pq = 50; with the integer form it fits but for 4-8 registers and buys
+    // nothing: 2 048 tags, sixteen / twelve per CU, L_pq = 50 1.71 / 1.72 ms, 100 3.02 / 3.09, 500 14.0 / 14.8, 1 000 36.3 / 34.9; dropped)
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = (W == 1) ? 0 : (int)(threadIdx.x >> 6);
     u64 *pool = reinterpret_cast<u64 *>(smem + p.off_pool);

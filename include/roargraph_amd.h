@@ -63,7 +63,9 @@ int roar_load_base_fbin(roar_index *idx, const char *path);
 /* Same, from caller memory: n rows of `dim` valid floats at `row_stride_floats` stride (host). */
 int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_stride_floats);
 /* Adopt rows already resident in HBM (no copy, caller keeps ownership and must outlive the index).
- * row_stride_floats must be a multiple of 4 and >= the padded dim with zero padding in place. */
+ * row_stride_floats must be a multiple of 4 and >= the padded dim with zero padding in place.
+ * The rows must not change while the index uses them: derived copies (the 8-bit screening copy, option "screen") are made
+ * from them on the first search; call this again after changing them. */
 int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats);
 
 /* ---- graph ----------------------------------------------------------------------------------

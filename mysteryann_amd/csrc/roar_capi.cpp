@@ -705,8 +705,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     sel.regpool = (L <= 64 && idx->pool_form == 0) ? 1 : 0;
     sel.prof = idx->profile ? 1 : 0;
     sel.hub = use_hub ? 1 : 0;
-    if (sel.prof && !(idx->ip && idx->dim_pad == 200))
-        return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product shape only");
+    if (sel.prof && !(idx->ip && idx->dim_pad == 200) && !(!idx->ip && idx->dim_pad == 128))
+        return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product and the 128-d L2 shapes only");
     int occ = 0;
     auto occupancy = [&](int *out) -> int {
         // (asked once per kernel form and LDS size: a stream of launches of one shape must not pay a runtime query each)

@@ -1069,7 +1069,7 @@ const void *pick_form(const RoarKernelSel &s) {
         if (s.waves == 2) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, false, false, true>;
         return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, true>;
     }
-    if (s.prof) {  // instrumented instantiations exist for the Text-to-Image shape only
+    if (s.prof) {  // instrumented instantiations exist for the Text-to-Image shape
         if constexpr (IP && NCH == 12) {
             if (s.waves == 4)
                 return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 4, true, true>
@@ -1077,6 +1077,10 @@ const void *pick_form(const RoarKernelSel &s) {
             if (s.waves == 2)
                 return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, true, true>
                           : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 2, false, true>;
+            return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, true>
+                      : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true>;
+        } else if constexpr (!IP && NCH == 8) {  // ... and, one wave per query, for the SIFT shape
+            if (s.waves != 1) return nullptr;
             return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, true>
                       : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true>;
         } else {

@@ -332,7 +332,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    distances, hops and cmps do not depend on it (csrc/roar_search_v2.h, screen8_pass).  Kernels: inner
  *                    product / cosine at 128, 200 and 512 floats per row, L2 at 128 and 512; auto = on for the 200-d and 512-d
  *                    ones (at 128-d a hop gathers too little for it to pay), 2 = on wherever there is a kernel
- *   "profile_phases" 1: instrumented kernel (200-d inner-product shape), see roar_last_profile
+ *   "profile_phases" 1: instrumented kernel (200-d inner-product and 128-d L2 shapes), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
  *                    threads while a launch is in flight share the next launch (the reference's harness calls

@@ -601,7 +601,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // profiles/r03_screen_forms.txt).
     const bool screen_sparse = p.screen != nullptr && !dense && !use_hub;
     // (512-d rows, WebVid-2.5M shape: 2 048 tags / HBM tags 70.1 / 79.5 ms at L_pq = 1 000, 100.1 / 106.7 at 1 400, 175.7 / 146.1 at 2 000)
-    const uint32_t lds_until = screen_sparse ? (idx->dim_pad >= 512 ? 1600u : 1300u) : use_hub ? 1200u : dense ? 512u : 1950u;
+    // (200-d, T2I-10M, final kernels: 2 048 tags / HBM tags 35.1 / 42-47 ms at L_pq = 1 000, 53.1-53.5 / 54.9-61.9 at 1 400, 102-103 / 85-88 at 2 000)
+    const uint32_t lds_until = screen_sparse ? (idx->dim_pad >= 512 ? 1600u : 1550u) : use_hub ? 1200u : dense ? 512u : 1950u;
     int mode = idx->visited_mode == ROAR_VISITED_AUTO
                    ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
                    : idx->visited_mode;

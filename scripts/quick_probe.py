@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/scripts")
 import torch
 from _graph import t2i_index
 idx, base, queries = t2i_index(10_000_000, 10000)
-for L in (50, 100, 200, 500, 1000, 1400, 2000):
+for L in [int(x) for x in os.environ.get("LS", "50,100,200,500,1000,1400,2000").split(",")]:
     row=[f"L={L}"]
     for mode,name in ((2,"auto"),(3,"forget"),(0,"exact")):
         idx.set_option("visited_mode", mode)

@@ -698,7 +698,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             arow = ADJ + (u64)p.ep * AS;
             a0 = arow[lane];
             a1 = arow[64 + lane];
-            a2 = arow[128 + lane];
+            if (AS > 128u) a2 = arow[128 + lane];  // (rows of up to 128 words end before the third chunk: two lines saved per fetch)
             if (HUB) a3 = arow[192 + lane];
             pf = p.ep;
             // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
@@ -770,7 +770,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         if (v != pf) {  // the speculative fetch went to another row: pay the round trip now
                             a0 = arow[lane];
                             a1 = arow[64 + lane];
-                            a2 = arow[128 + lane];
+                            if (AS > 128u) a2 = arow[128 + lane];
                             if (HUB) a3 = arow[192 + lane];
                             if (PROF) n_rt++;
                         } else if (PROF) {
@@ -865,7 +865,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         }
                         a0 = nrow[lane];
                         a1 = nrow[64 + lane];
-                        a2 = nrow[128 + lane];
+                        if (AS > 128u) a2 = nrow[128 + lane];
                         if (HUB) a3 = nrow[192 + lane];
                     }
                     if constexpr (SD > 0) {  // 8-bit screen (see screen8_pass), once the pool is full

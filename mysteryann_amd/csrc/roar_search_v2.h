@@ -696,10 +696,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         if (wid == 0) {
             // the entry point is always the first expansion: its adjacency row travels with its base row
             arow = ADJ + (u64)p.ep * AS;
+            // (plain form: the first 64 words only -- degree + up to 63 neighbours, the common case on a sparse graph; the other
+            // chunks follow once the degree says they hold neighbours.  Hub form: ids and slots, the whole row.)
             a0 = arow[lane];
-            a1 = arow[64 + lane];
-            if (AS > 128u) a2 = arow[128 + lane];  // (rows of up to 128 words end before the third chunk: two lines saved per fetch)
-            if (HUB) a3 = arow[192 + lane];
+            if (HUB) {
+                a1 = arow[64 + lane];
+                if (AS > 128u) a2 = arow[128 + lane];
+                a3 = arow[192 + lane];
+            }
             pf = p.ep;
             // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
             if (lane == 0) cid[0] = p.ep;
@@ -769,9 +773,11 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         vcur = v;
                         if (v != pf) {  // the speculative fetch went to another row: pay the round trip now
                             a0 = arow[lane];
-                            a1 = arow[64 + lane];
-                            if (AS > 128u) a2 = arow[128 + lane];
-                            if (HUB) a3 = arow[192 + lane];
+                            if (HUB) {
+                                a1 = arow[64 + lane];
+                                if (AS > 128u) a2 = arow[128 + lane];
+                                a3 = arow[192 + lane];
+                            }
                             if (PROF) n_rt++;
                         } else if (PROF) {
                             pf_hit++;
@@ -780,6 +786,9 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         if (HUB) {
                             nhub = deg >> 16;
                             deg &= 0xFFFFu;
+                        } else if (deg > 63u) {  // a long row: its other chunks (a second round trip, rare on a sparse graph)
+                            a1 = arow[64 + lane];
+                            if (deg > 127u) a2 = arow[128 + lane];
                         }
                         scanned += deg;
                         wpos = 0;
@@ -858,14 +867,18 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     // hop's merges put something in front of it the fetch is simply dropped (pf is compared at select).
                     {
                         const uint32_t *nrow = arow + wpos;
+                        bool whole = true;  // the rest of a long row: every chunk; the next row, plain form: its first chunk
                         if (wpos > deg) {
                             if constexpr (RP) pf = (nextv != NONE) ? nextv : vcur;  // (nothing left: any valid row)
                             else pf = (cur < psize) ? (uint32_t)pool[cur] >> 1 : vcur;
                             nrow = ADJ + (u64)pf * AS;
+                            whole = HUB;
                         }
                         a0 = nrow[lane];
-                        a1 = nrow[64 + lane];
-                        if (AS > 128u) a2 = nrow[128 + lane];
+                        if (whole) {
+                            a1 = nrow[64 + lane];
+                            if (AS > 128u) a2 = nrow[128 + lane];
+                        }
                         if (HUB) a3 = nrow[192 + lane];
                     }
                     if constexpr (SD > 0) {  // 8-bit screen (see screen8_pass), once the pool is full

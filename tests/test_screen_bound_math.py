@@ -1,0 +1,92 @@
+"""The 8-bit screen's bound, restated in numpy f32 and checked on the CPU against the reference's own distance code (the oracle's
+`dist_many` = distance.h, summation order and all): for every (row, query) pair, the lower bound the kernels compute
+(csrc/roar_search_v2.h screen8i_pass, csrc/roar_kernels.hip roar_make_screen8_kernel) must not exceed the distance the reference
+computes.  This pins the derivation where no GPU is present; the kernels themselves are tested pair by pair on the
+GPU (tests/test_gpu_parity.py::test_screen_never_drops_a_row_at_or_under_the_threshold)."""
+import numpy as np
+import pytest
+
+f32 = np.float32
+
+
+def bf16_up(v):
+    b = np.asarray(v, f32).view(np.uint32)
+    hi = (b >> 16) + ((b & 0xFFFF) != 0)
+    return (hi.astype(np.uint32) << 16).view(f32)
+
+
+def code_rows(x):
+    """roar_make_screen8_kernel: c, s, B, N per row (f32 arithmetic as the kernel's)."""
+    x = np.asarray(x, f32)
+    old = np.seterr(all="ignore")
+    mx = np.abs(x).max(axis=1)
+    bad = ~np.isfinite(x).all(axis=1) | (mx > f32(1e30)) | ((mx > 0) & (mx < f32(1e-30)))
+    s = (mx / f32(127)).astype(f32)
+    inv = np.where(mx > 0, f32(127) / np.where(mx > 0, mx, f32(1)), f32(0)).astype(f32)
+    c = np.clip(np.rint(x * inv[:, None]), -127, 127).astype(f32)
+    d = ((x - s[:, None] * c) * inv[:, None]).astype(f32)
+    e2 = (d * d).sum(axis=1, dtype=f32)
+    c2 = (c * c).sum(axis=1, dtype=f32)
+    nrm = (s * np.sqrt(c2) * f32(1.0001)).astype(f32)
+    bnd = (f32(1.001) * s * np.sqrt(e2) * f32(1.0001) + f32(1.2e-7) * nrm).astype(f32)
+    B, N = bf16_up(bnd), bf16_up(nrm)
+    B[bad], N[bad], s[bad], c[bad] = np.inf, 0, 0, 0
+    np.seterr(**old)
+    return c.astype(np.int32), s, B, N
+
+
+def code_query(q, D):
+    """screen8_query: k, |q| rounded up, t, E."""
+    q = np.asarray(q, f32)
+    mx, s2 = np.abs(q).max(), (q * q).sum(dtype=f32)
+    t = f32(mx / f32(127))
+    inv = f32(127) / mx if mx > 0 else f32(0)
+    k = np.clip(np.rint(q * inv), -127, 127).astype(f32)
+    d = ((q - t * k) * inv).astype(f32)
+    e2 = (d * d).sum(dtype=f32)
+    qa = f32(np.sqrt(s2) * f32(1.0001))
+    qc = f32(f32(1.001) * t * np.sqrt(e2) + (f32(4.0e-7) + f32(1.25) * f32(D // 16 + 6) * f32(5.9604645e-8)) * qa)
+    if not (mx <= 1e18) or not (s2 <= 3e38) or (0 < mx < 1e-30):
+        qa = f32(np.inf)
+    return k.astype(np.int32), qa, t, qc
+
+
+@pytest.mark.parametrize("d", [128, 200, 512])
+def test_lower_bound_never_exceeds_the_reference_distance(d):
+    import oracle
+
+    rng = np.random.default_rng(5)
+    n, nq = 3000, 48
+    x = rng.standard_normal((n, d)).astype(f32)
+    x[100:200, 3] *= 1e4
+    x[200:220] = 0
+    x[300:400] *= f32(1e-20)
+    x[400:500] *= f32(1e15)
+    x[500:600] = np.minimum(np.abs(np.rint(x[500:600] * 40)), 255)
+    x[600:620] = f32(3.25)
+    x[620:700] += f32(100)
+    x[700:800] = f32(1e-42)
+    q = rng.standard_normal((nq, d)).astype(f32)
+    q[0] = 0
+    q[1] = 0
+    q[1, 3] = 3
+    q[2] *= f32(1e-10)
+    q[3] *= f32(1e10)
+    q[4:8] = x[1000:1004]
+    q[8:12] = -x[1000:1004]
+    c, s, B, N = code_rows(x)
+    worst = -np.inf
+    dropped_at_5pc = []
+    for i in range(nq):
+        k, qa, t, qc = code_query(q[i], d)
+        I = (c.astype(np.int64) @ k.astype(np.int64)).astype(f32)  # exact: |I| < 2^24
+        with np.errstate(invalid="ignore", over="ignore"):
+            lower = (-((s * t) * I) - (qc * N + qa * B) - f32(1e-30)).astype(f32)
+        exact = oracle.dist_many(1, x, np.repeat(q[i][None], n, axis=0))  # -(x . q) as distance.h computes it
+        viol = lower > exact  # (NaN compares false: such a row is kept)
+        assert not viol.any(), (d, i, np.argwhere(viol)[:5].ravel(), lower[viol][:5], exact[viol][:5])
+        if i >= 12:
+            ordinary = np.arange(1100, n)
+            margin = 0.05 * np.linalg.norm(q[i].astype(np.float64)) * np.linalg.norm(x[ordinary].astype(np.float64), axis=1)
+            dropped_at_5pc.append(np.mean(lower[ordinary] > exact[ordinary] - margin))
+    assert np.mean(dropped_at_5pc) > 0.98  # and it is tight: 5 % of |q||x| under the exact distance, ordinary rows are dropped

@@ -90,3 +90,80 @@ def test_lower_bound_never_exceeds_the_reference_distance(d):
             margin = 0.05 * np.linalg.norm(q[i].astype(np.float64)) * np.linalg.norm(x[ordinary].astype(np.float64), axis=1)
             dropped_at_5pc.append(np.mean(lower[ordinary] > exact[ordinary] - margin))
     assert np.mean(dropped_at_5pc) > 0.98  # and it is tight: 5 % of |q||x| under the exact distance, ordinary rows are dropped
+
+
+def code_rows_l2(x):
+    """roar_make_screen8_l2_kernel: u (0..255), s, lo, |x~|^2, B per row."""
+    x = np.asarray(x, f32)
+    old = np.seterr(all="ignore")
+    n, d = x.shape
+    mx, mn = x.max(axis=1), x.min(axis=1)
+    bad = ~np.isfinite(x).all(axis=1) | (np.abs(x).max(axis=1) > f32(1e17))
+    rng_ = (mx - mn).astype(f32)
+    bad |= (rng_ > 0) & (rng_ < f32(1e-30))
+    rng_[bad] = 0
+    lo = np.where(bad, f32(0), mn).astype(f32)
+    tight = (rng_ / f32(255)).astype(f32)
+    mant, ex = np.frexp(tight)
+    p2 = np.where(tight > 0, np.ldexp(f32(1), np.where(mant == 0.5, ex - 1, ex)), 0).astype(f32)
+    out = []
+    for sc in (p2, tight):
+        inv = np.where(sc > 0, f32(1) / np.where(sc > 0, sc, f32(1)), f32(0)).astype(f32)
+        u = np.clip(np.rint((x - lo[:, None]) * inv[:, None]), 0, 255).astype(f32)
+        xh = np.float32(np.float64(sc[:, None]) * np.float64(u) + np.float64(lo[:, None]))  # (the kernel's fma: one rounding)
+        dd = ((x - xh) * inv[:, None]).astype(f32)
+        e2 = (dd * dd).sum(axis=1, dtype=f32)
+        n2 = (xh * xh).sum(axis=1, dtype=f32)
+        out.append((u, sc, e2, n2))
+    exact = out[0][2] == 0
+    u = np.where(exact[:, None], out[0][0], out[1][0])
+    sc = np.where(exact, out[0][1], out[1][1]).astype(f32)
+    e2 = np.where(exact, out[0][2], out[1][2]).astype(f32)
+    n2 = np.where(exact, out[0][3], out[1][3]).astype(f32)
+    B = (f32(1.001) * sc * np.sqrt(e2) * f32(1.0001) + f32(2.5e-7) * np.sqrt(n2) * f32(1.0001)).astype(f32)
+    B[bad], n2[bad], sc[bad], u[bad] = np.inf, 0, 0, 0
+    np.seterr(**old)
+    return u.astype(f32), sc, lo, n2, B
+
+
+@pytest.mark.parametrize("d", [128, 512])
+def test_l2_lower_bound_never_exceeds_the_reference_distance(d):
+    import oracle
+
+    rng = np.random.default_rng(6)
+    n, nq = 2500, 40
+    x = rng.standard_normal((n, d)).astype(f32)
+    x[100:200, 3] *= 1e4
+    x[200:220] = 0
+    x[300:400] *= f32(1e-20)
+    x[400:500] *= f32(1e15)
+    x[500:900] = np.minimum(np.abs(np.rint(x[500:900] * 40)), 255)  # SIFT-like: coded without error
+    x[900:920] = f32(3.25)
+    x[920:1000] += f32(100)
+    q = rng.standard_normal((nq, d)).astype(f32)
+    q[0] = 0
+    q[2] *= f32(1e-10)
+    q[3] *= f32(1e10)
+    q[4:8] = x[500:504] + rng.standard_normal((4, d)).astype(f32) * f32(0.5)
+    q[8:12] = x[920:924] + rng.standard_normal((4, d)).astype(f32) * f32(1e-3)  # the cancelling case
+    q[12:16] = x[1500:1504]
+    u, sc, lo, n2, B = code_rows_l2(x)
+    assert (B[500:900] < 1e-3).all()  # integer rows: the power-of-two scale codes them exactly
+    y = f32(d) ** f32(0.5)
+    kappa = f32(1.25 * (2.0 * d * (1.0 + float(y)) + d + 8.0) / 16777216.0 * 1.0001)
+    tight = []
+    for i in range(nq):
+        qa, qb = (q[i] * q[i]).sum(dtype=f32), q[i].sum(dtype=f32)
+        acc = (u @ q[i]).astype(f32)  # (any summation order: the allowance kappa is for the worst one)
+        with np.errstate(all="ignore"):
+            xq = (lo * qb + sc * acc).astype(f32)
+            dlo = ((n2 - f32(2) * xq + qa) - kappa * (n2 + qa) - f32(1e-30)).astype(f32)
+            tt = (np.sqrt(np.maximum(dlo, 0)) * f32(0.999999) - B).astype(f32)
+            lower = np.where(tt > 0, tt * tt * f32(0.99999), 0).astype(f32)
+        exact = oracle.dist_many(0, x, np.repeat(q[i][None], n, axis=0))  # sum (x - q)^2 as distance.h computes it
+        viol = lower > exact
+        assert not viol.any(), (d, i, np.argwhere(viol)[:5].ravel(), lower[viol][:5], exact[viol][:5])
+        if i >= 16:
+            o = np.arange(1100, n)
+            tight.append(np.mean(lower[o] > 0.9 * exact[o]))
+    assert np.mean(tight) > 0.98  # tight: within 10 % of the exact distance for ordinary rows

@@ -110,6 +110,32 @@ def build_reference_graph(torch, mi, idx, learn, n_exact, stage2_L, say=log):
             f"searched on it (k=100, L_pq={stage2_L}) -> BuildRoarGraph on all {n_learn} lists, M_sq=100 M_pjbp=35 L_pjpq=500")
 
 
+def implemented_bytes(rows_code, rows_f32, adj_words, queries, dim_padded, screen_row_bytes, k):
+    """Bytes the IMPLEMENTED algorithm asks the memory side for (the counters are the kernel's own,
+    roar_set_traffic_counters_device): every row scored on the 8-bit screening copy is one row of that copy, every row that reaches
+    the exact pass one f32 row, every adjacency fetch its whole 64-word chunks (speculative fetches that were dropped included),
+    + the query read and the result write.  SURVEY 8(d)'s formula with the reference's `4 D cmps` split into the two kinds of
+    row this kernel reads; visited-set traffic is excluded there and here."""
+    return (float(screen_row_bytes) * float(rows_code) + 4.0 * dim_padded * float(rows_f32) + 4.0 * float(adj_words)
+            + (4.0 * dim_padded + 8.0 * k) * float(queries))
+
+
+def kernel_trace_span(csv_path, steps, name="roar_search_v2_kernel"):
+    """(span ms, mean duration ms) of the last `steps` launches of the search kernel in a rocprofv3 kernel_trace.csv: span = last
+    end - first start (launches that overlap on several streams: span / steps is the effective time per launch)."""
+    import csv
+
+    rows = [x for x in csv.DictReader(open(csv_path)) if name in x["Kernel_Name"] and "build" not in x["Kernel_Name"]]
+    if len(rows) < steps:
+        raise RuntimeError(f"{len(rows)} traced launches of the search kernel in {csv_path}, expected at least {steps}")
+    rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+    rows = rows[-steps:]
+    t0 = min(int(x["Start_Timestamp"]) for x in rows)
+    t1 = max(int(x["End_Timestamp"]) for x in rows)
+    mean = sum(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows) / steps
+    return (t1 - t0) * 1e-6, mean * 1e-6
+
+
 def recall_at_k(torch, ids, gt, k):
     hit = (gt[:, :k, None] == ids[:, None, :k].to(torch.int64)).any(dim=2).sum().item()
     return hit / float(k * ids.shape[0])
@@ -153,8 +179,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="t2i", choices=["t2i", "webvid", "sift"],
-                    help="t2i = the BASELINE metric's configuration (default); webvid / sift = the other configs' shapes")
+    ap.add_argument("--workload", default="t2i", choices=["t2i", "webvid", "sift", "t2i-hard"],
+                    help="t2i = the BASELINE metric's configuration (default); webvid / sift = the other configs' shapes; t2i-hard = the "
+                         "t2i shape on an isotropic base set (latent = D, optionally a common offset: --hard-offset), the data the "
+                         "8-bit screen was NOT built for (mysteryann_amd/synth.py)")
+    ap.add_argument("--hard-offset", type=float, default=0.0,
+                    help="t2i-hard: common component of every base row, in units of the isotropic part's norm (a narrow cone)")
     ap.add_argument("--n", "--base-points", dest="n", type=int, default=0, help="base points (default: 10 M t2i, 2.5 M webvid, 1 M sift)")
     ap.add_argument("--nq", type=int, default=10_000, help="queries in one batch (the reference's query file: 10 000)")
     ap.add_argument("--batches", type=int, default=8,
@@ -230,6 +260,8 @@ def parse_args(argv=None):
                     help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of measure_traffic()
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-share-probe", action="store_true",
+                    help="N = 1: skip the emulated share of 8 (the timed loop once more over the first nq / 8 rows of every batch)")
     ap.add_argument("--no-screen", action="store_true", help="switch the 8-bit screening pass off (option screen = 1)")
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
     ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
@@ -250,7 +282,7 @@ def main():
     import numpy as np
     import torch
 
-    shape = {"t2i": (10_000_000, 200), "webvid": (2_500_000, 512), "sift": (1_000_000, 128)}[args.workload]
+    shape = {"t2i": (10_000_000, 200), "webvid": (2_500_000, 512), "sift": (1_000_000, 128), "t2i-hard": (10_000_000, 200)}[args.workload]
     args.n_explicit = args.n
     args.n = args.n or shape[0]
     args.dim = args.dim or shape[1]
@@ -282,6 +314,11 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     dev = torch.device("cuda", local)
+    ranks_seen = 1
+    if use_dist:  # a one-element all-reduce of ones over RCCL: how many ranks the collective really spans
+        t_ = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(t_)
+        ranks_seen = int(t_.item())
 
     from mysteryann_amd import index as mi
     from mysteryann_amd import parallel, synth
@@ -301,7 +338,8 @@ def main():
         n_exact = args.ref_learn or args.n // 5
         stage2 = args.ref_learn2 if args.ref_learn2 >= 0 else (args.n if args.workload == "t2i" else 0)
         n_learn = max(n_exact, stage2)
-    gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch}[args.workload]
+    gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch,
+           "t2i-hard": lambda *a, **kw: synth.t2i_hard_torch(*a, offset=args.hard_offset, **kw)}[args.workload]
     # B batches of nq queries in one draw; strong scaling: every rank draws the SAME block and takes its rows of each batch
     base, qall, learn = gen(args.n, args.nq * B, args.dim, seed=args.seed, n_learn=n_learn, device=dev,
                             query_seed=args.seed + 2 + (0 if strong else 1000 * rank))
@@ -359,8 +397,19 @@ def main():
         idx.set_option("screen", 1 if args.no_screen else 0)
         if args.vis_entries:
             idx.set_option("vis_entries", args.vis_entries)
+        # the timed loop's launches in the regime asked for: one after the other, or --in-flight launches overlapping on as many
+        # streams with the workgroup cap of the timed loop (a --pmc pass serialises dispatches: what it measures is the capped
+        # launch's traffic; a --kernel-trace pass lets them overlap and records every launch's start and end)
+        depth_c = max(1, args.in_flight)
+        streams_c = [torch.cuda.current_stream(dev)] if depth_c == 1 else [torch.cuda.Stream(dev) for _ in range(depth_c)]
+        if depth_c > 1 and args.launch_grid > 0:
+            idx.set_option("max_grid", args.launch_grid)
+        for st_ in streams_c:
+            idx.SearchRoarGraphBatchDevice(batches[0], args.k, args.L, stream=st_)
+        torch.cuda.synchronize()
         for s_ in range(args.warmup + args.steps):
-            idx.SearchRoarGraphBatchDevice(batches[s_ % B] if s_ >= args.warmup else batches[0], args.k, args.L)
+            idx.SearchRoarGraphBatchDevice(batches[s_ % B] if s_ >= args.warmup else batches[0], args.k, args.L,
+                                           stream=streams_c[s_ % depth_c])
         torch.cuda.synchronize()
         return
 
@@ -416,7 +465,7 @@ def main():
                 if not args.sweep:
                     break
         if chosen == 0:
-            chosen = L_LIST[-1]
+            chosen = max(L for L in L_LIST if L <= args.max_L)
             log(f"[rank {rank}] WARNING: recall target {args.target_recall} not reached, using L_pq={chosen}")
     if args.sweep and rank == 0:
         log("L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops")
@@ -433,16 +482,33 @@ def main():
                 f"cmps {float(o['cmps'].float().mean()):.0f}, grid {idx.info('last_grid')}, lds {idx.info('last_lds_bytes')}")
         idx.set_option("vis_entries", args.vis_entries)
 
-    # per batch: recall at the chosen L_pq, and the reference algorithm's counters (EXACT visited mode, untimed) for the
-    # roofline's algorithmic bytes
+    # per batch: recall at the chosen L_pq; the reference algorithm's counters (EXACT visited mode, untimed) for the
+    # reference-priced bytes; and what the timed launch itself asks the memory side for (the counting instantiation of the same
+    # kernel on the same launch plan, untimed: rows on the 8-bit copy, rows on the f32 rows, adjacency words)
     dpad = idx.info("dim_padded")
-    recalls, alg_bytes, same_ids = [], [], True
+    srow = idx.info("screen_row_bytes")
+    recalls, alg_bytes, impl_bytes, same_ids = [], [], [], True
     ref_cmps = ref_hops = ref_scan = lds_cmps = 0.0
+    rows_code = rows_f32 = adj_words = rows_passed = 0.0
+    counters_equal = True
     outs = []
+    tblock = torch.zeros((mine, 4), dtype=torch.int32, device=dev)
     for b in range(B):
         o = run(chosen, b)
         torch.cuda.synchronize()
         recalls.append(global_recall(o["ids"], gts[b]))
+        idx.SetTrafficCounters(tblock)
+        oc = run(chosen, b)
+        torch.cuda.synchronize()
+        idx.SetTrafficCounters(None)
+        tb = tblock.to(torch.float64).sum(dim=0)
+        counters_equal = counters_equal and all(bool((oc[key_] == o[key_]).all().item()) for key_ in ("ids", "dists", "cmps", "hops"))
+        impl_bytes.append(implemented_bytes(tb[0].item(), tb[1].item(), tb[2].item(), mine, dpad, srow, args.k))
+        rows_code += tb[0].item() / B / mine
+        rows_f32 += tb[1].item() / B / mine
+        adj_words += tb[2].item() / B / mine
+        # rows the screen let through = rows on f32 - entry point - neighbours that never saw the screen
+        rows_passed += (tb[1].item() - mine - (oc["cmps"].double().sum().item() - tb[0].item())) / B / mine
         idx.set_option("visited_mode", 0)
         ex = run(chosen, b)
         torch.cuda.synchronize()
@@ -458,6 +524,7 @@ def main():
         lds_cmps += o["cmps"].double().mean().item() / B
         outs.append(o)
     rec = float(np.mean(recalls))
+    screen_pass_rate = (rows_passed / rows_code) if rows_code > 0 else None
 
     main_stream = torch.cuda.current_stream(dev)
     depth_wanted = args.in_flight if args.in_flight > 0 else 6
@@ -549,10 +616,39 @@ def main():
         idx.set_option("max_grid", 0)
         batches, outs = keep_b, keep_o
         weak_value = world * args.nq * args.steps / wall_w
-    bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    # ---- one GPU's share of the batch at N = 8, measured on this GPU (N = 1 only): the same K steps over the first nq / 8 rows of
+    # every batch, the same depth, the cap of a rank's share -- what the strong-scaling run at N = 8 asks of each rank
+    share8 = None
+    if world == 1 and strong and args.nq >= 64 and not args.no_share_probe:
+        sh = args.nq // 8
+        keep_b, keep_o = batches, outs
+        batches = [qall[b_ * args.nq:b_ * args.nq + sh].contiguous() for b_ in range(B)]
+        outs = [idx.SearchRoarGraphBatchDevice(batches[b_], args.k, chosen) for b_ in range(B)]
+        torch.cuda.synchronize()
+        share_grid = args.launch_grid if args.launch_grid >= 0 else 640
+        idx.set_option("max_grid", share_grid if depth > 1 else 0)
+        wall_s8, gpu_s8 = timed(lambda s_: s_ % B, depth)
+        idx.set_option("max_grid", 0)
+        wall_s8_1, _ = timed(lambda s_: s_ % B)
+        batches, outs = keep_b, keep_o
+        share8 = {"queries_per_launch": sh, "launches_in_flight": depth, "workgroups_per_launch_cap": share_grid if depth > 1 else 0,
+                  "ms_per_step": wall_s8 * 1e3 / args.steps, "ms_per_step_one_launch_at_a_time": wall_s8_1 * 1e3 / args.steps,
+                  "projected_value_8_gpus": args.nq * args.steps / wall_s8,
+                  "projected_speedup_over_this_run": (args.nq * args.steps / wall_s8) / qps,
+                  "note": "a projection from ONE GPU: the first nq / 8 rows of every batch on this GPU stand for one of eight ranks"}
 
-    screened = bool(idx.info("last_screen"))
+    ref_bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
+    bytes_per_launch = float(np.mean([impl_bytes[s_ % B] for s_ in range(args.steps)]))
+    # `value` is measured with `depth` launches in flight; the roofline line is stated in THAT regime: the effective duration of a
+    # launch = GPU span of the K timed launches / K (HIP events on the launch streams: recorded on the main stream, which the
+    # side streams wait for and which waits for them).  The one-launch-at-a-time figures stand beside it.
+    eff_ms = gpu_pipe / args.steps
+    achieved = bytes_per_launch / (eff_ms * 1e-3) / 1e9
+    achieved_serial = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    regime = (f"{depth} launches in flight on {depth} streams, at most {pipe_grid} workgroups each: kernel_ms = GPU span of the {args.steps} "
+              f"timed launches / {args.steps} (HIP events on the launch streams)") if depth > 1 else \
+        "one launch at a time: kernel_ms = HIP events around the timed launches / steps"
+
     result = {
         "metric": "QPS @ recall@10=0.9, Text-to-Image-10M OOD" if (args.workload, args.n) == ("t2i", 10_000_000)
         else f"QPS @ recall@10={args.target_recall}, {args.workload} shape",
@@ -568,34 +664,53 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "t2i-10M-ip" if (args.workload, args.n) == ("t2i", 10_000_000)
-                   else f"{args.workload}-shape-n{args.n}", "n_base": args.n,
+                   else f"{args.workload}-shape-n{args.n}" + (f"-offset{args.hard_offset:g}" if args.workload == "t2i-hard" else ""),
+                   "n_base": args.n,
                    "dim": args.dim, "metric": "l2" if metric == mi.L2 else "ip", "n_queries_total": total_q,
                    "n_queries_per_gpu": mine, "k": args.k, "L_pq": chosen, "recall_at_10": rec,
                    "recall_at_10_min_over_batches": float(min(recalls)),
+                   "value_regime": regime.split(":")[0],
+                   "screen_pass_rate": screen_pass_rate,
+                   "rccl_ranks_seen": ranks_seen,
                    "query_batches_rotated": B, "ms_per_step_same_batch_replayed": wall_replay * 1e3 / args.steps,
                    "launches_in_flight": depth, "workgroups_per_launch_cap_in_flight": pipe_grid,
                    "value_with_a_whole_batch_per_rank_and_step_weak_scaling": weak_value, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
                    "value_one_launch_at_a_time": total_q * args.steps / wall_serial,
+                   "emulated_share_of_8": share8,
                    "parallelism": (f"index replicated on {world} GPU(s); one {args.nq}-query batch per step split by query, "
                                    f"rank r searches rows [r nq/N, (r+1) nq/N); no collective" if strong else
                                    f"index replicated on {world} GPU(s); every rank its own {args.nq}-query batch; no collective"),
                    "visited": visited_desc,
-                   "screen": (f"8-bit codes of the base rows ({ {200: 256, 512: 528, 128: 144}.get(args.dim, 0) } B per row) scored first; a neighbour is dropped there only if its exact key is "
+                   "screen": (f"8-bit codes of the base rows ({srow} B per row) scored first; a neighbour is dropped there only if its exact key is "
                               "certainly above the reject threshold; the others are scored on the f32 rows: ids, distances, hops, cmps unchanged")
                    if idx.info("last_screen") else "off",
                    "waves_per_query": idx.info("last_waves_per_query"), "register_pool": bool(idx.info("last_register_pool")),
                    "builder": args.builder, "index": index_desc, "graph_hash": f"{graph_hash:016x}",
                    "avg_degree": idx.info("nedges") / args.n, "adjacency_stride_words": idx.info("adj_stride"),
                    "build_seconds": build_s},
+        # (the driver's record keeps the first keys of this object: what the line means comes first)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     # other yardsticks for the same number: the measured streaming-copy rate of the guide, and this
-                     # access pattern's own ceiling (uniformly random 800-B rows, profiles/r01_fetch_calibration.txt)
-                     "frac_vs_6.29_TBs_streaming_copy": achieved / 6290.0,
-                     "frac_vs_4.9_TBs_random_row_ceiling": achieved / 4900.0,
-                     "kernel": "roar_search_v2_kernel", "kernel_ms": kernel_ms, "kernel_ms_same_batch_replayed": gpu_replay / args.steps,
-                     "last_launch_ms": last_kernel_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "queries_per_launch": mine,
+                     "kernel": "roar_search_v2_kernel", "kernel_ms": eff_ms, "regime": regime,
+                     "requested_bytes_frac_of_peak": None, "l2_hit_share": None,
+                     "frac_le_1": bool(achieved / HBM_PEAK_GBS <= 1.0),
+                     "bytes_per_launch": bytes_per_launch,
+                     "bytes": "IMPLEMENTED algorithm, from the kernel's own per-query counters: screen_row_bytes x rows scored on the 8-bit copy "
+                              "+ 4 D_pad x rows scored on the f32 rows + 4 x adjacency words fetched (dropped speculative fetches included) "
+                              "+ (4 D_pad + 8 k) per query; visited-set traffic excluded (SURVEY 8(d))",
+                     "one_launch_at_a_time": {"kernel_ms": kernel_ms, "achieved": achieved_serial, "frac": achieved_serial / HBM_PEAK_GBS,
+                                              "traffic": None, "requested_bytes_frac_of_peak": None,
+                                              "last_launch_ms": last_kernel_ms,
+                                              "kernel_ms_same_batch_replayed": gpu_replay / args.steps},
+                     # the same launches priced in the REFERENCE algorithm's bytes (4 D per distance evaluation, reference
+                     # cmps / hops / scanned): a rate the memory system never sees when the screen keeps most f32 rows from being read
+                     "reference_bytes_speedup": ref_bytes_per_launch / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "reference_bytes_per_launch": ref_bytes_per_launch,
+                     "reference_bytes_over_implemented_bytes": ref_bytes_per_launch / bytes_per_launch,
+                     "queries_per_launch": mine,
+                     "rows_on_8bit_copy_per_query": rows_code, "rows_on_f32_per_query": rows_f32,
+                     "adjacency_words_per_query": adj_words, "screen_row_bytes": srow if rows_code > 0 else 0,
+                     "counting_kernel_results_equal_timed_kernel": counters_equal,
                      "avg_cmps": ref_cmps, "avg_hops": ref_hops, "avg_scanned": ref_scan,
                      "kernel_cmps": lds_cmps, "grid": idx.info("last_grid"),
                      "kernel_ms_with_exact_on_chip_visited_set": exact_form_ms, "kernel_cmps_with_exact_on_chip_visited_set": exact_form_cmps,
@@ -603,28 +718,43 @@ def main():
                      "lds_bytes": idx.info("last_lds_bytes"), "ids_equal_exact_mode": same_ids,
                      # north_star asks for MFMA utilisation beside HBM GB/s: this kernel is GEMV shaped
                      # (0.5 flop/B) and issues no MFMA; the repo's MFMA kernel is the exact-kNN generator
-                     # (knn_pass_kernel, 0.57 of the f32 peak, MFMA pipes 60 % busy: profiles/r01_counters.txt)
                      "mfma_util": 0.0},
     }
+    if not result["roofline"]["frac_le_1"]:
+        log(f"[rank {rank}] ERROR: roofline.frac = {achieved / HBM_PEAK_GBS:.3f} > 1: the launch cannot have moved {bytes_per_launch / 1e9:.2f} GB "
+            f"from HBM in {eff_ms:.3f} ms -- cache hits (small set?) or a counting error")
 
-    # HBM traffic per launch.  PMC counters cannot be read from inside the process, so rank 0 of a one-GPU run profiles a
-    # child of itself: `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --pmc-child ...` and the same for
-    # WRITE_SIZE (the two do not fit one pass), same data (seed), same graph (file), same L_pq, same rotating batches.
-    # If that is not possible here the figure of a stored capture of the same command (scripts/profile_r2.sh ->
-    # profiles/*_search_kernel_summary.json) is quoted for the same workload, L_pq and graph hash; else null.
+    # HBM traffic per launch.  PMC counters cannot be read from inside the process, so rank 0 of a one-GPU run profiles
+    # children of itself (`rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --pmc-child ...`, the same for
+    # WRITE_SIZE -- the two do not fit one pass -- and an L2 set), same data (seed), same graph (file), same L_pq, same rotating
+    # batches: once with the launches of the regime `value` is measured in (depth streams, capped grid), once one launch at
+    # a time; and one --kernel-trace pass (no counters: launches really overlap) for the span of the overlapped launches.
     if world == 1 and rank == 0 and not args.no_traffic:
         try:
             t0 = time.time()
-            tr = measure_traffic(args, idx, chosen, mine)
-            if tr:
-                result["roofline"].update(tr)
-                # `achieved` / `frac` price the launch in the REFERENCE algorithm's bytes (4 D per distance evaluation), so
-                # they can exceed the peak when the screen keeps most f32 rows from being read at all; the bytes the launch really
-                # asked the memory side for, over the same time, are these:
-                result["roofline"]["requested_bytes_rate_GBs"] = tr["traffic"] / (kernel_ms * 1e-3) / 1e9
-                result["roofline"]["requested_bytes_frac_of_peak"] = tr["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                log(f"[rank 0] PMC traffic per launch {tr['traffic'] / 1e9:.2f} GB = {tr['traffic'] / bytes_per_launch:.3f} x algorithmic "
-                    f"({time.time() - t0:.0f}s for the two profiled child passes)")
+            tr = measure_traffic(args, idx, chosen, mine, depth, pipe_grid)
+            rf = result["roofline"]
+            if tr.get("in_flight"):
+                t_ = tr["in_flight"]
+                rf.update({k_: v_ for k_, v_ in t_.items() if k_ != "traffic_source"})
+                rf["traffic_source"] = t_["traffic_source"]
+                rf["requested_bytes_frac_of_peak"] = t_["traffic"] / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rf["frac_over_requested_bytes_frac"] = rf["frac"] / rf["requested_bytes_frac_of_peak"]
+            if tr.get("serial"):
+                t_ = tr["serial"]
+                one = rf["one_launch_at_a_time"]
+                one["traffic"] = t_["traffic"]
+                one["l2_hit_share"] = t_.get("l2_hit_share")
+                one["requested_bytes_frac_of_peak"] = t_["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if rf["traffic"] is None:  # (no in-flight passes: the serial figure stands for both)
+                    rf["traffic"], rf["l2_hit_share"] = t_["traffic"], t_.get("l2_hit_share")
+                    rf["requested_bytes_frac_of_peak"] = t_["traffic"] / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    rf["traffic_source"] = t_["traffic_source"]
+            if tr.get("trace"):
+                rf["rocprof_kernel_trace"] = tr["trace"]
+            if rf["traffic"]:
+                log(f"[rank 0] PMC traffic per launch {rf['traffic'] / 1e9:.2f} GB = {rf['traffic'] / bytes_per_launch:.3f} x implemented-algorithm "
+                    f"bytes = {rf['traffic'] / ref_bytes_per_launch:.3f} x reference-priced bytes ({time.time() - t0:.0f}s for the profiled child passes)")
         except Exception as e:  # noqa: BLE001
             log(f"[rank 0] PMC traffic not measured in this run: {e}")
     try:
@@ -667,11 +797,14 @@ def counter_per_launch(csv_path, counter, steps):
     return sum(float(x["Counter_Value"]) for x in rows[-steps:]) / steps
 
 
-def measure_traffic(args, idx, L, nq_launch):
-    """FETCH_SIZE / WRITE_SIZE of the search kernel's timed launches, from two profiled child runs of this script
+def measure_traffic(args, idx, L, nq_launch, depth=1, pipe_grid=0):
+    """FETCH_SIZE / WRITE_SIZE (+ an L2 set) of the search kernel's timed launches, from profiled child runs of this script
     (MI355X_MICROARCH.md: separate --pmc passes with --kernel-trace only; FETCH_SIZE counts 128-B requests at 64 B on
-    gfx950 -> x2, calibrated on this access pattern in profiles/r01_fetch_calibration.txt).  The child is started as a
-    child process (never exec'ed over this one), the interpreter itself after `--`."""
+    gfx950 -> x2, calibrated on this access pattern in profiles/r01_fetch_calibration.txt).  Two regimes: the one `value` is
+    measured in (`depth` streams, at most `pipe_grid` workgroups per launch; a --pmc pass serialises dispatches, so what it
+    sees is the capped launch alone) and one launch at a time; plus one --kernel-trace pass without counters, where the
+    launches really overlap: their span.  Children are started as child processes (never exec'ed over this one), the interpreter
+    itself after `--`.  -> {"in_flight": {...} | None, "serial": {...}, "trace": {...} | None}"""
     import glob, shutil, subprocess, tempfile
 
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -684,37 +817,51 @@ def measure_traffic(args, idx, L, nq_launch):
         os.close(fd)
         idx.SaveProjectionGraph(cache)
     steps = 8
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
-             "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
-             "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
-             "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0"] + (["--no-screen"] if args.no_screen else [])
+    child0 = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
+              "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
+              "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
+              "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0",
+              "--hard-offset", str(args.hard_offset)] + (["--no-screen"] if args.no_screen else [])
     env = dict(os.environ, TMPDIR="/tmp")
-    vals = {}
-    try:
-        # third pass: where the bytes come from -- L2 hits / misses and the L2's memory-side read requests (all / those routed
-        # to the memory controllers).  Optional: a box whose profiler refuses the set just leaves these fields out.
-        L2SET = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum")
+    L2SET = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum")
+
+    def profiled(child, names):
+        """one rocprofv3 run of `child`; names = counters of a --pmc pass, or () for --kernel-trace alone -> output dir"""
+        out = tempfile.mkdtemp(prefix="roar_pmc_", dir="/tmp")
+        cmd = [prof, "--kernel-trace"] + (["--pmc"] + list(names) if names else []) + ["--output-format", "csv", "-d", out, "--"] + child
+        # own session: a timeout must end the profiler AND the profiled child, not just the former
+        pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            _, err = pr.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            import signal
+
+            os.killpg(pr.pid, signal.SIGKILL)  # (the exact process group started above)
+            pr.communicate()
+            shutil.rmtree(out, ignore_errors=True)
+            raise RuntimeError(f"rocprofv3 {names or 'kernel-trace'} timed out")
+        if pr.returncode != 0:
+            shutil.rmtree(out, ignore_errors=True)
+            raise RuntimeError(f"rocprofv3 {names or 'kernel-trace'} failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}")
+        return out
+
+    def counters(child, what):
+        vals = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE", L2SET):
-            out = tempfile.mkdtemp(prefix="roar_pmc_", dir="/tmp")
             names = [counter] if isinstance(counter, str) else list(counter)
             try:
-                # own session: a timeout must end the profiler AND the profiled child, not just the former
-                pr = subprocess.Popen([prof, "--kernel-trace", "--pmc"] + names + ["--output-format", "csv", "-d", out, "--"] + child,
-                                      cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
-                try:
-                    _, err = pr.communicate(timeout=900)
-                except subprocess.TimeoutExpired:
-                    import signal
-
-                    os.killpg(pr.pid, signal.SIGKILL)  # (the exact process group started above)
-                    pr.communicate()
-                    raise RuntimeError(f"rocprofv3 --pmc {counter} timed out")
+                out = profiled(child, names)
+            except RuntimeError as e:
+                if counter is L2SET:  # optional: a box whose profiler refuses the set just leaves these fields out
+                    log(f"[rank 0] L2 counter pass not available here: {e}")
+                    continue
+                raise
+            try:
                 files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-                if pr.returncode != 0 or not files:
+                if not files:
                     if counter is L2SET:
-                        log(f"[rank 0] L2 counter pass not available here: rc {pr.returncode} {err.decode(errors='replace')[-200:]}")
                         continue
-                    raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}")
+                    raise RuntimeError(f"rocprofv3 --pmc {counter}: no counter file")
                 for nm in names:
                     try:
                         vals[nm] = counter_per_launch(max(files, key=os.path.getmtime), nm, steps)  # (SIZE counters: KB per launch)
@@ -723,24 +870,44 @@ def measure_traffic(args, idx, L, nq_launch):
                             raise
             finally:
                 shutil.rmtree(out, ignore_errors=True)
+        extra = {}
+        if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals and vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"] > 0:
+            extra["l2_hit_share"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])  # of 128-B line requests at the L2
+            extra["beyond_l2_bytes"] = vals["TCC_MISS_sum"] * 128.0  # what the L2 asks the fabric for: Infinity Cache + HBM together
+            extra["l2_requests_per_launch"] = vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]
+        if "TCC_EA0_RDREQ_sum" in vals and vals.get("TCC_EA0_RDREQ_sum", 0) > 0 and "TCC_EA0_RDREQ_DRAM_sum" in vals:
+            extra["l2_read_requests_routed_to_memory_controllers_share"] = vals["TCC_EA0_RDREQ_DRAM_sum"] / vals["TCC_EA0_RDREQ_sum"]
+        if extra:
+            # the Infinity Cache (256 MB, memory side) sits BEHIND these counters: a hit there is still an L2 miss and a
+            # memory-side read request, so HBM-only bytes are not separable with the counters rocprofv3 lists on gfx950
+            extra["frac_hbm_only"] = None
+        return {"traffic": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, **extra,
+                "traffic_source": f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {steps} launches of a "
+                                  f"child of this command (same data, graph, L_pq, batches; {what}); FETCH_SIZE x 2 (gfx950)",
+                "FETCH_SIZE_KB_raw_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw_per_launch": vals["WRITE_SIZE"]}
+
+    res = {"in_flight": None, "serial": None, "trace": None}
+    try:
+        flight = ["--in-flight", str(depth), "--launch-grid", str(pipe_grid)]
+        if depth > 1:
+            res["in_flight"] = counters(child0 + flight, f"launch plan of the timed loop: at most {pipe_grid} workgroups; the counter "
+                                                          f"passes serialise the launches")
+        res["serial"] = counters(child0 + ["--in-flight", "1"], "one launch at a time, uncapped grid")
+        try:  # launches overlapping for real: start / end of every launch from the kernel trace
+            out = profiled(child0 + (flight if depth > 1 else ["--in-flight", "1"]), ())
+            try:
+                files = glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True)
+                span, mean = kernel_trace_span(max(files, key=os.path.getmtime), steps)
+                res["trace"] = {"launches": steps, "in_flight": depth, "span_ms": span, "span_ms_per_launch": span / steps,
+                                "mean_launch_duration_ms": mean}
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
+        except Exception as e:  # noqa: BLE001
+            log(f"[rank 0] kernel-trace pass of the overlapped loop not available: {e}")
     finally:
         if own_cache and os.path.exists(cache):
             os.remove(cache)
-    extra = {}
-    if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals and vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"] > 0:
-        extra["l2_hit_share"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])  # of 128-B line requests at the L2
-        extra["beyond_l2_bytes"] = vals["TCC_MISS_sum"] * 128.0  # what the L2 asks the fabric for: Infinity Cache + HBM together
-        extra["l2_requests_per_launch"] = vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]
-    if "TCC_EA0_RDREQ_sum" in vals and vals.get("TCC_EA0_RDREQ_sum", 0) > 0 and "TCC_EA0_RDREQ_DRAM_sum" in vals:
-        extra["l2_read_requests_routed_to_memory_controllers_share"] = vals["TCC_EA0_RDREQ_DRAM_sum"] / vals["TCC_EA0_RDREQ_sum"]
-    if extra:
-        # the Infinity Cache (256 MB, memory side) sits BEHIND these counters: a hit there is still an L2 miss and a
-        # memory-side read request, so HBM-only bytes are not separable with the counters rocprofv3 lists on gfx950
-        extra["frac_hbm_only"] = None
-    return {**extra, "traffic": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
-            "traffic_source": f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {steps} launches of a "
-                              f"child of this command (same data, graph, L_pq, batches); FETCH_SIZE x 2 (gfx950)",
-            "FETCH_SIZE_KB_raw_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw_per_launch": vals["WRITE_SIZE"]}
+    return res
 
 
 def host_buffer_path(np, torch, idx, batches, outs, args, L):
@@ -859,8 +1026,15 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
     torch.cuda.synchronize()
     idx.set_option("visited_mode", 2)
     dpad = idx.info("dim_padded")
-    alg_bytes = (4 * dpad * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum() + 8 * ex["hops"].double().sum()
+    ref_bytes = (4 * dpad * ex["cmps"].double().sum() + 4 * ex["scanned"].double().sum() + 8 * ex["hops"].double().sum()
                  + (4 * dpad + 8 * k) * nq).item()
+    tblock = torch.zeros((nq, 4), dtype=torch.int32, device=dev)  # what the timed launch itself fetches (counting instantiation)
+    idx.SetTrafficCounters(tblock)
+    idx.SearchRoarGraphBatchDevice(queries, k, chosen)
+    torch.cuda.synchronize()
+    idx.SetTrafficCounters(None)
+    tb = tblock.to(torch.float64).sum(dim=0)
+    alg_bytes = implemented_bytes(tb[0].item(), tb[1].item(), tb[2].item(), nq, dpad, idx.info("screen_row_bytes"), k)
     for _ in range(args.warmup):
         step(chosen)
     torch.cuda.synchronize()
@@ -895,7 +1069,12 @@ def run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist):
                    "builder": args.builder, "avg_degree": idx.info("nedges") / m},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "roar_search_v2_kernel (this rank's shard)", "kernel_ms": kernel_ms,
-                     "exchange_and_merge_ms": ms_per_step - kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "regime": "one launch per step on this rank's shard: kernel_ms = HIP events around the last launch",
+                     "frac_le_1": bool(achieved / HBM_PEAK_GBS <= 1.0),
+                     "exchange_and_merge_ms": ms_per_step - kernel_ms, "bytes_per_launch": alg_bytes,
+                     "bytes": "IMPLEMENTED algorithm (kernel's own counters: rows on the 8-bit copy, rows on f32, adjacency words)",
+                     "reference_bytes_speedup": ref_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "reference_bytes_per_launch": ref_bytes,
                      "queries_per_launch": nq, "mfma_util": 0.0},
     }
     if rank == 0:

@@ -44,7 +44,7 @@ enum {
  * ids / distances / hops are identical to the reference in every mode; cmps is the reference's in EXACT and LDS and can
  * only be >= it in LDS_FORGETFUL.  (If HBM cannot hold one spill list per resident workgroup -- 2 n bytes each -- an LDS
  * launch runs forgetful; info key "last_visited_forgetful" says so.) */
-enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the fastest form for the launch -- LDS_FORGETFUL up to L_pq ~ 500-1950 (by the graph's density and the hub form, csrc/roar_capi.cpp plan_search), EXACT beyond */, ROAR_VISITED_LDS_FORGETFUL = 3 };
+enum { ROAR_VISITED_EXACT = 0, ROAR_VISITED_LDS = 1, ROAR_VISITED_AUTO = 2 /* default: the fastest form for the launch, measured on the loaded index (option "calibrate") -- LDS_FORGETFUL for short and medium pools, EXACT for the longest */, ROAR_VISITED_LDS_FORGETFUL = 3 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------
  * IndexBipartite::IndexBipartite(dimension, n, metric, nullptr)  src/index_bipartite.cpp:30-38,
@@ -65,7 +65,7 @@ int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_s
 /* Adopt rows already resident in HBM (no copy, caller keeps ownership and must outlive the index).
  * row_stride_floats must be a multiple of 4 and >= the padded dim with zero padding in place.
  * The rows must not change while the index uses them: derived copies (the 8-bit screening copy, option "screen") are made
- * from them on the first search; call this again after changing them. */
+ * from them in this call; call it again after changing them. */
 int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats);
 
 /* ---- graph ----------------------------------------------------------------------------------
@@ -312,8 +312,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  * Parameters::Set / Get  include/efanna2e/parameters.h:15-57 carry L_pq per call in the reference;
  * here L_pq is an argument and the remaining knobs are integers:
  *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_LDS_FORGETFUL | ROAR_VISITED_AUTO (default AUTO)
- *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow, at most six
- *                    with the on-chip tag table and rows of 768 bytes or more)
+ *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
@@ -324,14 +323,22 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    on-chip bitmap (a hub-annotated copy of the adjacency is made on first use; graphs with a row
  *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on dense graphs (same measure);
  *                    results do not depend on it
- *   "screen"         0 auto | 1 off | 2 on: the index keeps a second copy of the base rows in 8-bit codes (made on first use:
+ *   "screen"         0 auto | 1 off | 2 on: the index keeps a second copy of the base rows in 8-bit codes (made when the base rows are set:
  *                    200-d rows 256 bytes = two 128-byte lines instead of seven, 512-d rows 528 bytes = five lines instead of
  *                    sixteen) and a hop scores its unvisited neighbours on it first; a neighbour whose exact key is CERTAINLY
  *                    above the pool's reject threshold (rigorous bound: this row's quantisation error norm + the rounding of
  *                    the screen's own arithmetic) is dropped there, the others are scored on the f32 rows as before -- ids,
  *                    distances, hops and cmps do not depend on it (csrc/roar_search_v2.h, screen8_pass).  Kernels: inner
- *                    product / cosine at 128, 200 and 512 floats per row, L2 at 128 and 512; auto = on for the 200-d and 512-d
- *                    ones (at 128-d a hop gathers too little for it to pay), 2 = on wherever there is a kernel
+ *                    product / cosine at 128, 200 and 512 floats per row, L2 at 128 and 512; auto = decided by measurement on the loaded
+ *                    index and the caller's own queries (option "calibrate": the bound's power to drop rows is a property of the data --
+ *                    on sets whose scores are bunched within the bound's slack it passes nearly everything and costs a second
+ *                    dependent round trip for nothing), 2 = on wherever there is a kernel
+ *   "calibrate"      1 (default): what no option fixes -- screen on / off, visited form, table size -- is MEASURED on the loaded index:
+ *                    the first search of a (L_pq band, batch-size band, grid cap) times 5-8 candidate plans on the first (at most
+ *                    12 288) queries of that call, results into scratch buffers, and keeps the fastest for the launches that follow
+ *                    (that call synchronises its stream; results never depend on the plan; ROAR_LOG_CALIBRATION=1 in the environment
+ *                    prints every decision); 0: fixed defaults (screen on for rows of 768 bytes and more, the on-chip table with
+ *                    4 096 / 8 192 tags up to L_pq = 1 536, HBM tags beyond); 2: forget what was measured so far
  *   "profile_phases" 1: instrumented kernel (200-d inner-product and 128-d L2 shapes), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
@@ -341,7 +348,9 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
  *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
  *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
- *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "last_visited_forgetful", "last_kernel_ns"
+ *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "screen_row_bytes" (bytes per
+ *   row of the 8-bit screening copy at this dimension), "last_visited_forgetful", "last_plan_calibrated" (1 if the most recent search ran a measured plan),
+ *   "calibrations" (launch kinds measured so far), "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */
 int roar_set_option(roar_index *idx, const char *key, int64_t value);
@@ -353,6 +362,17 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value);
  * speculative adjacency fetches that were used, adjacency round trips paid, then wave 0's scoring passes: cycles
  * {issuing loads, waiting + FMAs, reduction + packing}, number of passes, candidates that reached the merge; 3 spare. */
 int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq);
+
+/* Measurement (no reference counterpart; SURVEY 8(d) prices a query by the counters the reference returns, cmps and hops,
+ * src/index_bipartite.cpp:2397,2419 -- with the 8-bit screen most of those distance evaluations never read their f32 row, so the
+ * kernel also counts what it really asks the memory side for): while a block is set, every SearchRoarGraph launch of this index
+ * with nq <= capacity_queries writes, for query q, counters_dev[4 q ..] = {rows scored on the 8-bit screening copy, rows scored
+ * on the f32 rows (entry point included; equals cmps + 1 with the screen off), adjacency words fetched (whole 64-word chunks,
+ * speculative next-row fetches that were dropped included), 0}.  Device memory, 16-byte aligned, caller owned; NULL switches
+ * it off.  Launches that overlap write the same rows: set it for untimed, one-at-a-time launches.  The counting form exists for
+ * one wave per query with device-resident or pinned queries: any other launch fails with ROAR_ERR_ARG while a block is set
+ * (option "search_kernel" = 1).  Hub-bitmap form: a row fetch is four chunks (ids + bitmap slots). */
+int roar_set_traffic_counters_device(roar_index *idx, uint32_t *counters_dev, uint64_t capacity_queries);
 
 /* Testing hook for the error paths: the n-th device allocation the library makes from now on fails as if HBM were
  * exhausted (n <= 0 disarms; ROAR_FAIL_AT=n in the environment arms it at load).  Returns how many allocations were still

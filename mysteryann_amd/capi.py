@@ -30,6 +30,7 @@ SYMBOLS = [
     "roar_rebase_ids_device", "roar_sharded_create", "roar_sharded_destroy", "roar_sharded_shard",
     "roar_sharded_set_id_base", "roar_search_batch_sharded", "roar_sharded_info", "roar_host_register",
     "roar_host_unregister", "roar_debug_fail_device_alloc_at", "roar_debug_screen_keeps",
+    "roar_set_traffic_counters_device",
 ]
 
 
@@ -129,6 +130,7 @@ def lib():
                                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     l.roar_debug_fail_device_alloc_at.argtypes = [C.c_int64]
     l.roar_debug_screen_keeps.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, fp, C.c_uint32, C.POINTER(C.c_uint8)]
+    l.roar_set_traffic_counters_device.argtypes = [vp, vp, C.c_uint64]
     l.roar_host_register.argtypes = [vp, C.c_uint64]
     l.roar_host_unregister.argtypes = [vp]
     l.roar_rebase_ids_device.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]

@@ -79,6 +79,14 @@ extern "C" int roar_launch_queue_trace(uint32_t capacity, uint32_t n_ops, const 
 extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim,
                             int ip, uint32_t k, uint32_t cap, void *cand, void *cursor, void *tau, void *bnorm,
                             void *overflow_dev, uint32_t *ids, float *dists, uint32_t *overflowed, void *stream);
+extern "C" {  // roar_knn_bf16.hip
+uint32_t roar_knn_bf16_row_quads(uint32_t dim);
+int roar_knn_bf16_convert(const float *src, uint64_t ld, uint32_t dim, uint64_t n, uint64_t n_pad, void *dst, float *sqnorm, uint32_t *max_sq_bits,
+                          void *stream);
+int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim, int ip, uint32_t k,
+                      uint32_t cap, const void *bb, const float *bnorm, void *qb, void *cand, void *cursor, void *tau, void *ea, void *kq,
+                      void *overflow_dev, uint32_t *rerank_rows_dev, uint32_t *ids, float *dists, uint32_t *overflowed, void *stream);
+}
 
 namespace {
 
@@ -138,6 +146,22 @@ struct roar_index {
     int screen_mode = 0;  // option "screen": 0 auto (on where it pays), 1 off, 2 on wherever the kernels have it
     int launch_events = 1;  // option "launch_events": 0 = no timing events around a launch ("last_kernel_ns" then keeps its last value)
     int last_screen = 0;
+    // What a launch plan leaves open when no option fixes it -- screen on / off, visited form, table size -- is MEASURED on the loaded
+    // index: the first search of a (L_pq band, batch-size band, grid cap) times the candidates on the first queries of that call and
+    // the winner is kept here (calibrate_plan).  Option "calibrate" = 0: fixed defaults instead.
+    struct Calibration {
+        uint64_t key;
+        int screen, mode;
+        uint32_t entries;
+        float best_ms, default_ms;
+        uint32_t sample, L, runs;
+    };
+    std::vector<Calibration> plan_cache;
+    int calibrate = 1;
+    int last_calibrated = 0;
+    int knn_mode = 0;  // option "knn_mode": 0 auto (bf16 MFMA screen + exact f32 re-rank where the row length allows), 1 f32 MFMA only
+    int last_knn_bf16 = 0;
+    int64_t last_knn_rerank_rows = 0;  // rows that reached the exact re-rank in the last roar_exact_knn_device call, all queries together
     uint64_t n = 0;
     uint32_t ld = 0;
     // graph in HBM (fixed-stride rows) + host CSR copy for save / get
@@ -179,6 +203,9 @@ struct roar_index {
     int profile = 0;        // 1: instrumented kernel, phase timers readable with roar_last_profile
     unsigned long long *prof_dev = nullptr;
     uint64_t prof_cap = 0, prof_nq = 0;
+    // caller's per-query traffic counters (roar_set_traffic_counters_device): u32[traffic_cap][4], not owned
+    uint32_t *traffic_dev = nullptr;
+    uint64_t traffic_cap = 0;
     bool building = false;  // searches issued by roar_build_graph run under their own kernel symbol
     RoarKernelSel last_sel = {};
     // workspaces
@@ -262,6 +289,7 @@ int use_device(roar_index *idx) {
 }
 
 void free_graph(roar_index *idx) {
+    idx->plan_cache.clear();  // (measured on the graph that goes away)
     if (idx->adj) (void)hipFree(idx->adj);
     idx->adj = nullptr;
     if (idx->adj_hub) (void)hipFree(idx->adj_hub);
@@ -285,6 +313,7 @@ void free_bipartite(roar_index *idx) {
 }
 
 void free_base(roar_index *idx) {
+    idx->plan_cache.clear();
     if (idx->screen) (void)hipFree(idx->screen);
     idx->screen = nullptr;
     idx->screen_n = 0;
@@ -512,15 +541,32 @@ void ensure_screen(roar_index *idx) {
     idx->screen_n = idx->n;
 }
 
+// The copy is made when the base rows arrive (one conversion pass), not inside the first search that wants it.
+void make_screen_with_base(roar_index *idx) {
+    const bool kernel = idx->dim_pad == 128 || idx->dim_pad == 512 || (idx->ip && idx->dim_pad == 200);
+    if (kernel && idx->screen_mode != 1 && (idx->screen_mode == 2 || idx->dim_pad * 4u >= 768u)) ensure_screen(idx);
+}
+
 struct LaunchPlan {
     RoarSearchParams p;
     RoarKernelSel sel;
     uint32_t grid;
 };
 
+// The three things a plan leaves to measurement (roar_index::Calibration); -1 / 0 = not decided: plan_search's defaults.
+struct PlanPick {
+    int screen = -1;       // 0 off, 1 on
+    int mode = -1;         // ROAR_VISITED_EXACT | ROAR_VISITED_LDS (under AUTO: the forgetful form)
+    uint32_t entries = 0;  // tags of the on-chip table
+};
 
-// LDS carve-up and grid for one search launch.
-int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan, bool bipartite = false) {
+// does this index have a screening kernel for its rows (roar_search_v2.h: 128-d and 512-d rows, 200-d inner product)
+inline bool has_screen_kernel(const roar_index *idx) {
+    return idx->dim_pad == 128 || idx->dim_pad == 512 || (idx->ip && idx->dim_pad == 200);
+}
+
+// LDS carve-up and grid for one search launch.  `pick`: measured choices for what no option fixes (null: defaults).
+int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan, bool bipartite = false, const PlanPick *pick = nullptr) {
     if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "search before base vectors were loaded");
     if (bipartite) {
         if (!idx->bp_off) return fail(ROAR_ERR_ARG, "search before the bipartite graph was loaded");
@@ -540,15 +586,21 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.ld = idx->ld;
     p.dim = idx->dim_pad;
     idx->last_screen = 0;
-    // The kernels have the screen for 128-d and 512-d rows (both metrics) and 200-d inner product.  AUTO leaves it off at 128-d: a
-    // hop there gathers too few bytes for the second dependent round trip to pay (SIFT-1M shape, 10 000 queries, off / on:
-    // L_pq = 50 2.07 / 4.23 ms, 170 6.78 / 12.8, 500 15.5 / 31.9 ms; 512-d, WebVid-2.5M shape: 95 14.2 / 6.75, 500 69.7 / 33.1,
-    // 2 000 295 / 146 ms; 200-d, T2I-10M: 50 3.45 / 1.80, 2 000 127 / 91 ms).
-    const bool screen_kernel = idx->dim_pad == 128 || idx->dim_pad == 512 || (idx->ip && idx->dim_pad == 200);
-    if (!bipartite && screen_kernel && idx->screen_mode != 1 && (idx->screen_mode == 2 || idx->dim_pad != 128)) {
-        ensure_screen(idx);
-        p.screen = idx->screen;
-        idx->last_screen = idx->screen ? 1 : 0;
+    // The 8-bit screen: option "screen" 1 = off, 2 = on; AUTO: what the calibration measured for this kind of launch, else (no
+    // calibration: option, builder's searches) on for rows of 768 bytes and more -- at 128-d a hop gathers too few bytes for the
+    // second dependent round trip to pay on any set measured (SIFT-1M shape, off / on: L_pq = 170 6.78 / 12.8 ms).
+    {
+        bool want_screen = false;
+        if (!bipartite && has_screen_kernel(idx) && idx->screen_mode != 1) {
+            if (idx->screen_mode == 2) want_screen = true;
+            else if (pick && pick->screen >= 0 && !idx->building) want_screen = pick->screen != 0;
+            else want_screen = idx->dim_pad * 4u >= 768u;
+        }
+        if (want_screen) {
+            ensure_screen(idx);
+            p.screen = idx->screen;
+            idx->last_screen = idx->screen ? 1 : 0;
+        }
     }
     p.adj = idx->adj;
     p.adj_stride = idx->adj_stride;
@@ -557,25 +609,14 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.nq = (uint32_t)nq;
     p.k = k;
     p.L = L;
-    // Long pools.  What pays depends on how many rows a hop gathers: a dense graph (the bootstrap builder's: average
-    // degree 33, hub rows of 128, ~97 rows scored per hop) saturates HBM with 4-5 waves per CU and has LDS to spare; a
-    // sparse one (the reference-shaped builder's: average degree 16, ~49 rows per hop) needs its 8 waves per CU.
-    //   dense graph, L_pq >= 100: hub-bitmap form -- the 65 535 highest-in-degree nodes keep their visited bits in an
-    //     exact LDS bitmap, the tag table / the HBM tags see only the other neighbours.  T2I-10M bootstrap graph,
-    //     10 000 queries, best plain form -> best hub form: L_pq = 100 9.96 -> 9.91 ms, 300 23.99 -> 23.42, 500 37.60 ->
-    //     36.85, 700 60.5 -> 49.6, 1 000 85.7 -> 68.5, 1 400 105.7 -> 91.3, 2 000 142.2 -> 128.6 ms; 1 250 queries:
-    //     300 3.74 -> 3.28, 500 5.95 -> 5.19, 1 000 11.3 -> 9.31, 2 000 19.6 -> 17.5 ms.  The on-chip table (4 096 tags
-    //     from L_pq = 500) then beats the HBM tags up to L_pq ~ 1 200 (1 000: 68.5 vs 74.1 ms; 1 400: 92.7 vs 91.3 ms).
-    //   sparse graph: the plain form with 8 192 tags up to L_pq = 1 500 (4 096 to 1 950), HBM tags beyond.  T2I-10M reference-shaped
-    //     graph, 10 000 queries, 8 192 tags / 4 096 tags + hub bitmap / 16 384 tags / HBM tags: L_pq = 100 6.17 / 6.14 /
-    //     6.63 / 7.82 ms, 500 26.0 / 26.1 / 28.4 / 33.8, 1 000 55.0 / 55.6 / 74.8 / 63.9, 1 400 78.3 / 79.0 / 108.9 / 85.7,
-    //     2 000 131.0 / 134.7 / 162.9 / 116.0 ms (profiles/r02_hub_forms*.txt).
-    // ("dense" is about the bytes a hop gathers -- average degree x row bytes, with 24 rows of 800 B as the line: a
-    // 128-d graph of average degree 32 gathers 16 KB per hop and behaves like a sparse one: SIFT-1M shape, L_pq = 170,
-    // hub form with five waves per CU 9.59 ms, plain form with eight 8.0 ms)
-    // With the screening copy a hop gathers the 8-bit rows of its neighbours and the f32 rows of the few that pass: every graph
-    // measured behaves like a sparse one (WebVid-2.5M shape, average degree 43, 10 000 queries, plain form with 4 096 tags / hub form
-    // at its best table: L_pq = 95 6.78 / 7.33 ms, 200 13.4 / 14.3, 500 33.2 / 39.7 ms).
+    // Hub-bitmap form (long pools on graphs whose hops gather many bytes): the 65 535 highest-in-degree nodes keep their visited
+    // bits in an exact LDS bitmap, the tag table / the HBM tags see only the other neighbours.  It needs a second copy of the
+    // adjacency (seconds to make, once per graph), so it is not a calibration candidate but a structural rule: "dense" =
+    // average degree x row bytes >= 24 x 800 B per hop, without the screen (with it a hop gathers the 8-bit rows of its
+    // neighbours and the f32 rows of the few that pass: every graph measured then behaves like a sparse one).  T2I-10M bootstrap
+    // graph (average degree 33, ~97 rows per hop), 10 000 queries, best plain form -> best hub form: L_pq = 100 9.96 -> 9.91 ms,
+    // 500 37.60 -> 36.85, 1 000 85.7 -> 68.5, 2 000 142.2 -> 128.6 ms (profiles/r02_hub_forms*.txt); a 128-d graph of average
+    // degree 32 gathers 16 KB per hop and behaves like a sparse one (SIFT-1M shape, L_pq = 170: hub form 9.59 ms, plain 8.0 ms).
     const bool dense = !p.screen && idx->gn && (double)idx->nedges / (double)idx->gn * (double)idx->dim_pad * 4.0 >= 24.0 * 800.0;
     bool use_hub = false;
     if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
@@ -583,29 +624,22 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         if (e) return e;
         use_hub = idx->hub_state == 1;
     }
-    // AUTO: the on-chip tag table for short and medium pools, HBM epoch tags beyond (without the hub bitmap a dense
-    // graph overruns the table from L_pq ~ 500: LDS 49.1 vs EXACT 50.7 ms at 500, 250 vs 126 ms at 1 500)
+    // Visited form.  An option fixes it; under AUTO it is what the calibration measured on this index (the on-chip tag table,
+    // forgetful, against u8 epoch tags in HBM: the table wins while the pool's nodes mostly fit it, the HBM tags beyond -- where
+    // "beyond" starts depends on the graph, the row length and the screen: L_pq ~ 500 ... 1 950 on the sets measured so far,
+    // profiles/r02_hub_forms*.txt, r03_screen_forms.txt, r04_calibration.txt).  Without a measurement (option "calibrate" = 0,
+    // the builder's searches): the table up to L_pq = 1 536.
     // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
     const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;
     // (the two-hop walk touches an order of magnitude more distinct nodes per hop: the 8192-tag table forgets
     // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
     // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
-    // (sparse graph, L_pq 1 500 ... 1 900: a 4 096-tag table with six workgroups per CU re-scores 50 % more rows than the
-    // reference and still beats the HBM tags, 82.1 / 87.6 / 93.1 / 98.5 ms against 85.1 / 91.5 / 96.1 / 101.0 ms at L_pq = 1 500 /
-    // 1 600 / 1 700 / 1 800; at 2 000 the HBM tags win, 111.9 against 116.9 ms; scripts/long_pool_probe.py)
-    // With the 8-bit screen (200-d inner product) a hop is two dependent gathers of far fewer bytes and the launch lives on
-    // resident workgroups: the small tables win everywhere (twelve workgroups per CU, the register limit) and the HBM tags --
-    // also twelve per CU -- take over earlier.  T2I-10M default graph, 10 000 queries, 8 192 / 4 096 / 2 048 tags / HBM tags:
-    // L_pq = 50 2.15 / 1.81 / 1.83 / 3.04 ms, 100 4.31 / 3.50 / 3.62 / 5.57, 200 8.99 / 6.82 / 6.85 / 10.3, 500 25.8 / 19.9 / 17.4 / 23.9,
-    // 1 000 63.8 / 43.5 / 38.5 / 45.1, 1 400 92.9 / 73.1 / 64.2 / 61.8, 2 000 165 / 142 / 122 / 91.3 ms (scripts/quick_probe.py,
-    // profiles/r03_screen_forms.txt).
-    const bool screen_sparse = p.screen != nullptr && !dense && !use_hub;
-    // (512-d rows, WebVid-2.5M shape: 2 048 tags / HBM tags 70.1 / 79.5 ms at L_pq = 1 000, 100.1 / 106.7 at 1 400, 175.7 / 146.1 at 2 000)
-    // (200-d, T2I-10M, final kernels: 2 048 tags / HBM tags 35.1 / 42-47 ms at L_pq = 1 000, 53.1-53.5 / 54.9-61.9 at 1 400, 102-103 / 85-88 at 2 000)
-    const uint32_t lds_until = screen_sparse ? (idx->dim_pad >= 512 ? 1600u : 1550u) : use_hub ? 1200u : dense ? 512u : 1950u;
-    int mode = idx->visited_mode == ROAR_VISITED_AUTO
-                   ? ((L < lds_until && lds_fits && !bipartite) ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT)
-                   : idx->visited_mode;
+    int mode = idx->visited_mode;
+    if (mode == ROAR_VISITED_AUTO) {
+        if (bipartite || !lds_fits) mode = ROAR_VISITED_EXACT;
+        else if (pick && pick->mode >= 0 && !idx->building) mode = pick->mode == ROAR_VISITED_EXACT ? ROAR_VISITED_EXACT : ROAR_VISITED_LDS;
+        else mode = L < 1536u ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT;
+    }
     // LDS: the exact form (ids that find their set full go to the spill list in HBM); LDS_FORGETFUL: a full set overwrites
     // a victim (cmps >= the reference's, nothing stored to HBM); the builder's searches and the two-hop walk forget
     // AUTO takes the forgetful form wherever it takes the table at all: it is the faster one at every L_pq on both benchmark
@@ -622,35 +656,16 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // one-wave form wins, 99 vs 113 ms); an explicit visited_mode keeps the one-wave form with that mode
     const bool bp_wg = bipartite && idx->visited_mode == ROAR_VISITED_AUTO && L <= 200;
     idx->last_mode = mode;
-    // visited table size: power of two, sets >= n / 65535 so that the u16 tag is exact
+    // visited table size: sets (2^k or 3 * 2^k) >= n / 65535 so that the u16 tag is exact.  It trades forgetting against resident
+    // workgroups -- which way pays depends on the graph, the row length, L_pq and the batch: option "vis_entries", else what the
+    // calibration measured, else 8 192 tags (4 096 with the screen or with rows under 768 bytes: such launches live on resident
+    // workgroups).
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
     bool sets3 = false;
     if (mode == ROAR_VISITED_LDS) {
-        // auto: 8192 tags (16 KB, 8 waves per CU) at short pools and for batches that do not fill the chip; 16384 tags
-        // (32 KB, 4 waves per CU) once the pool is long enough for the small table to forget and there are queries
-        // enough to keep four waves per CU busy.  T2I-10M, 10 000 queries, 8192 / 16384 / 32768 tags: L_pq = 100
-        // 10.49 / 9.97 / 14.26 ms, 300: 26.79 / 24.05 / 35.45 ms, 500: 43.32 / 37.74 / 55.95 ms (cmps 36.5 k / 29.9 k
-        // against the reference's 27.0 k); 2 500 queries: 100: 2.81 / 2.87, 300: 7.21 / 7.04, 500: 11.61 / 11.02 ms;
-        // 1 250 queries: the small table wins everywhere (profiles/r02_kernel_forms.txt).  L_pq = 60: 6.09 vs 7.26 ms.
-        // With the hub bitmap the table holds the non-hub neighbours only: 8 192 tags below L_pq = 500, 4 096 beyond (LDS is
-        // then better spent on resident waves: 1 250 queries at L_pq = 500, 5.19 ms with 4 096 tags, 6.90 ms with 8 192).
-        // Sparse graph, medium pools: 12 288 tags (3 x 1 024 sets) while five workgroups of that size fit a CU's LDS
-        // (L_pq <= 530: 1 280-byte LDS blocks) -- T2I-10M default graph, 8 192 -> 12 288 tags: 10 000 queries at L_pq = 300 / 400 / 500 15.90 -> 15.81 /
-        // 20.81 -> 20.58 / 25.76 -> 25.32 ms (cmps at 500: 21.4 k -> 20.4 k, reference 19.0 k), 1 250 queries 2.26 -> 2.18 /
-        // 2.94 -> 2.83 / 3.62 -> 3.45 ms; at L_pq = 200 and from 700 on (four per CU) the small table wins.
-        uint32_t want = 8192u;
-        if (!use_hub && !dense && L >= 250 && L <= 530) want = 12288u;
-        if (!use_hub && !dense && L >= 1500) want = 4096u;
-        // rows under 768 bytes: a hop gathers little, the launch lives on resident waves -- the small table buys twelve
-        // workgroups per CU instead of seven (SIFT-1M shape, L_pq = 170, 2 048 / 4 096 / 8 192 / 16 384 tags: 6.94 / 6.31 / 6.99 /
-        // 10.03 ms with 8 184 / 7 218 / 6 645 / 6 473 scored rows per query)
-        if (!use_hub && !dense && idx->dim_pad * 4u < 768u) want = 4096u;
-        // (512-d: two waves per SIMD is the register limit, the 4 096-tag table costs no residency up to L_pq ~ 900:
-        // WebVid shape, 2 048 / 4 096 / 8 192 tags: L_pq = 95 7.16 / 6.78 / 7.21 ms, 200 13.9 / 13.4 / 13.9, 500 34.3 / 33.2 / 38.2 ms)
-        if (screen_sparse) want = (L < 300 || (idx->dim_pad >= 512 && L <= 900)) ? 4096u : 2048u;
-        if (use_hub) want = L < 500 ? 8192u : 4096u;
-        else if (dense && ((L >= 250 && nq >= 2048) || (L >= 100 && nq >= 6000))) want = 16384u;
+        uint32_t want = (p.screen || idx->dim_pad * 4u < 768u) ? 4096u : 8192u;
+        if (pick && pick->entries > 0 && !idx->building && !bipartite) want = pick->entries;
         if (idx->vis_entries > 0) want = (uint32_t)idx->vis_entries;
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
@@ -678,7 +693,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     p.off_vis = off;
     off += 2 * entries;
     p.off_ctrl = off;
-    off += 64;  // (words 0-5 multi-wave hand-over, 6 spill epoch, 8-9 query norm / sum for the screen)
+    off += 64;  // (words 0-5 multi-wave hand-over, 6 spill epoch, 8-10 the query's side of the screen, 12-13 traffic counters)
     if (use_hub) {  // row buffer + bitmap of the hub form
         p.off_rowbuf = off;
         off += 1024;
@@ -776,17 +791,9 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     }
     if (occ < 1) occ = 1;
     int wpc = idx->waves_per_cu > 0 ? std::min(idx->waves_per_cu, occ) : occ;
-    // One-wave workgroups with the on-chip tag table: six per CU, not the eight the LDS allows -- the launch is bound by
-    // the memory system either way and the extra waves only add contention for it (T2I-10M default graph, 10 000 queries,
-    // 5 / 6 / 7 / 8 per CU: L_pq = 55 3.585 / 3.593 / 3.603 / 3.635 ms, 100 6.09 / 5.98 / 6.03 / 6.11 ms; 2 500 queries at
-    // L_pq = 55 0.973 / 0.997 / 0.970 / 1.021 ms).  EXACT mode wants every wave it can get (its tag probes are latency).
-    // Rows of 768 bytes and more only: with 512-byte rows (SIFT-1M shape, L_pq = 170, 28 fresh rows per hop) a wave has too
-    // little in flight and the seventh workgroup is worth 13 % (1.34 -> 1.51 M QPS).
-    // With the screen a hop is two dependent gathers of fewer bytes: the launch is bound by latency again and takes every
-    // workgroup the LDS and the registers allow.
-    if (idx->waves_per_cu == 0 && mode == ROAR_VISITED_LDS && sel.waves == 1 && !bipartite && !idx->building &&
-        idx->dim_pad * 4u >= 768u && !p.screen)
-        wpc = std::min(wpc, 6);
+    // (Rounds 2-3 launched six one-wave workgroups per CU with the on-chip table and no screen although the LDS allows eight: 1 % on the
+    // 10 M-point benchmark -- 3.593 against 3.635 ms -- and a handicap wherever a launch is bound by latency, e.g. any set that fits the
+    // caches; the cap went with the other constants measured on one graph.  Option "waves_per_cu" still sets it.)
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
     if (grid > nq) grid = nq;
     if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;
@@ -822,7 +829,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
             forget = true;
         }
     }
-    if (mode == ROAR_VISITED_LDS && forget) p.vis_sets_log2 |= 0x40000000u;
+    // (the two-hop kernels always forget and read the field as a plain shift count: the flag is the search kernel's)
+    if (mode == ROAR_VISITED_LDS && forget && !bipartite) p.vis_sets_log2 |= 0x40000000u;
     idx->last_forgetful = (mode == ROAR_VISITED_LDS && forget) ? 1 : 0;
     p.counter = idx->counters;
     if (sel.prof) {
@@ -1040,6 +1048,7 @@ int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_s
         }
         if ((e = upload_rows(idx, buf.data(), r0, cnt))) return e;
     }
+    make_screen_with_base(idx);
     return ROAR_OK;
 }
 
@@ -1057,6 +1066,7 @@ int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uin
     idx->base_owned = false;
     idx->n = n;
     idx->ld = row_stride_floats;
+    make_screen_with_base(idx);
     return ROAR_OK;
 }
 
@@ -1108,6 +1118,7 @@ int roar_load_base_fbin(roar_index *idx, const char *path) {
         }
     }
     fclose(f);
+    make_screen_with_base(idx);
     return ROAR_OK;
 }
 
@@ -1681,6 +1692,255 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
 }
 
 namespace {
+
+// ---- launch-plan calibration -----------------------------------------------------------------------------------------------
+// Which of {8-bit screen on / off} x {on-chip tag table of 2 048 ... 16 384 tags, HBM epoch tags} is fastest depends on the
+// graph's degree distribution, the row length, the data (how many neighbours the screen's bound can drop), L_pq and the batch
+// size.  Rounds 1-3 carried a table of thresholds measured on two synthetic graphs; now the index measures itself: the first
+// search of a (L_pq band, batch band, grid cap) runs the candidates on the first queries of that very call -- results into scratch
+// buffers, each candidate timed with HIP events on the caller's stream -- and keeps the winner.  Results never depend on the plan
+// (ids / distances / hops are the reference's in every form), so a calibration can only cost time: 5-8 launches over at most
+// 12 288 queries, once per band.  Options that fix a choice ("screen", "visited_mode", "vis_entries") take it out of the search;
+// "calibrate" = 0 switches the whole thing off (plan_search's defaults).  ROAR_LOG_CALIBRATION=1 prints every decision.
+// (a sample of 4 096 queries -- a third more than one residency of the chip -- misjudged the 10 000-query launch: 8 192 tags looked 5 %
+// faster than 4 096 on it and were 8 % slower on the whole batch, where the table's cost is resident workgroups; T2I-10M, L_pq = 50)
+constexpr uint32_t CAL_SAMPLE = 12288;  // four residencies of the chip (3 072 single-wave workgroups at twelve per CU)
+
+bool calibratable(const roar_index *idx) {
+    if (!idx->calibrate || idx->building || idx->profile) return false;
+    const bool screen_free = idx->screen_mode == 0 && has_screen_kernel(idx);
+    const bool mode_free = idx->visited_mode == ROAR_VISITED_AUTO;
+    const bool entries_free = idx->vis_entries == 0 && (idx->visited_mode == ROAR_VISITED_AUTO || idx->visited_mode == ROAR_VISITED_LDS ||
+                                                        idx->visited_mode == ROAR_VISITED_LDS_FORGETFUL);
+    return screen_free || mode_free || entries_free;
+}
+
+uint64_t plan_key(const roar_index *idx, uint64_t nq, uint32_t L) {
+    uint32_t lband = 0;  // half-octave bands of L_pq: [2^(b/2), 2^((b+1)/2))
+    while (lband < 40 && std::pow(2.0, 0.5 * (lband + 1)) <= (double)L) lband++;
+    // batch bands by queries per CU: 1, 2, 4, 6, 8, 10, 12, more -- fine around the residency limit (6-12 single-wave workgroups per CU
+    // by LDS and registers), where a table's size decides whether the whole batch is resident (1 250 and 2 500 queries want different
+    // tables on the benchmark graph: 0.415 / 0.431 ms with 8 192 / 4 096 tags against 0.719 / 0.559 ms)
+    const uint64_t cus = (uint64_t)std::max(idx->n_cus, 1);
+    const uint64_t per_cu = (nq + cus - 1) / cus;
+    const uint32_t nqband = per_cu <= 1 ? 0u : per_cu <= 2 ? 1u : per_cu <= 4 ? 2u : per_cu <= 6 ? 3u : per_cu <= 8 ? 4u : per_cu <= 10 ? 5u : per_cu <= 12 ? 6u : 7u;
+    uint32_t gband = 0;  // cap on the grid ("max_grid"): 0 = none, else its octave
+    for (uint64_t g = (uint64_t)std::max(idx->max_grid, 0); g; g >>= 1) gband++;
+    return (uint64_t)lband | ((uint64_t)nqband << 8) | ((uint64_t)gband << 12) | ((uint64_t)(idx->waves_per_cu & 0xFF) << 20);
+}
+
+const roar_index::Calibration *find_calibration(const roar_index *idx, uint64_t key) {
+    for (const auto &c : idx->plan_cache)
+        if (c.key == key) return &c;
+    return nullptr;
+}
+
+int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st);
+
+// -> *out = the fastest candidate for launches like this one (and a cache entry); on anything that keeps the measurement from
+// running (no memory for the scratch results, a candidate that cannot be planned) the defaults stand and nothing is cached.
+int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st,
+                   PlanPick *out, bool *calibrated) {
+    *calibrated = false;
+    const uint64_t key = plan_key(idx, nq, L);
+    const uint32_t S = (uint32_t)std::min<uint64_t>(nq, CAL_SAMPLE);
+    uint32_t *sc_ids = nullptr;
+    if (roar_dev_malloc((void **)&sc_ids, (size_t)S * k * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return ROAR_OK;
+    }
+    float *sc_d = reinterpret_cast<float *>(sc_ids + (size_t)S * k);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipFree(sc_ids);
+        return ROAR_OK;
+    }
+    const bool log = getenv("ROAR_LOG_CALIBRATION") != nullptr;
+    const bool had_tags = idx->tags != nullptr;
+    uint32_t runs = 0;
+    int hard_error = ROAR_OK;
+    // one candidate: planned for the sample, launched, timed; short launches twice (the faster counts: the first launch of a
+    // kernel form also pays its code-object load).  -> ms, or a negative value if the candidate cannot run here
+    auto time_pick = [&](const PlanPick &pk, uint32_t *entries_used, int *mode_used, int *screen_used) -> float {
+        float best = -1.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            LaunchPlan pl;
+            const std::string keep = g_err;
+            int e = plan_search(idx, S, k, L, &pl, false, &pk);
+            if (e) {
+                g_err = keep;
+                if (e == ROAR_ERR_DEVICE) hard_error = e;
+                return -1.f;
+            }
+            if (entries_used) *entries_used = (uint32_t)idx->last_vis_entries;
+            if (mode_used) *mode_used = idx->last_mode;
+            if (screen_used) *screen_used = idx->last_screen;
+            pl.p.queries = qdev;
+            pl.p.qstride = qstride;
+            pl.p.out_ids = sc_ids;
+            pl.p.out_dists = sc_d;
+            if (hipEventRecord(e0, st) != hipSuccess) return -1.f;
+            if ((e = launch_planned(idx, pl, st))) {
+                hard_error = e;
+                return -1.f;
+            }
+            float ms = 0.f;
+            if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+                hard_error = fail(ROAR_ERR_DEVICE, "calibration launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return -1.f;
+            }
+            runs++;
+            best = best < 0.f ? ms : std::min(best, ms);
+            if (ms > 4.0f) break;
+        }
+        return best;
+    };
+    const bool screen_free = idx->screen_mode == 0 && has_screen_kernel(idx);
+    const bool mode_free = idx->visited_mode == ROAR_VISITED_AUTO;
+    const bool lds_possible = idx->visited_mode != ROAR_VISITED_EXACT && (idx->n + 65533) / 65534 <= 2048;
+    const bool entries_free = idx->vis_entries == 0 && lds_possible;
+    struct Cand {
+        PlanPick pk;
+        float ms;
+        uint32_t entries;
+        int mode, screen;
+    };
+    std::vector<Cand> tried;
+    tried.reserve(16);
+    auto try_pick = [&](int screen, int mode, uint32_t entries) -> const Cand * {
+        PlanPick pk;
+        pk.screen = screen, pk.mode = mode, pk.entries = entries;
+        Cand c{pk, -1.f, 0, 0, 0};
+        c.ms = time_pick(pk, &c.entries, &c.mode, &c.screen);
+        if (c.ms < 0.f) return nullptr;
+        for (const Cand &o : tried)  // (a table below the minimum for this many points is planned as the minimum: the same launch)
+            if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen) return nullptr;
+        if (log)
+            fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: screen %s, %s, %u tags: %.3f ms\n", L, S, c.screen ? "on" : "off",
+                    c.mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", c.entries, c.ms);
+        tried.push_back(c);
+        return &tried.back();
+    };
+    // the default plan first: what a launch without calibration would have run (the yardstick in the log)
+    PlanPick none;
+    float default_ms = -1.f;
+    {
+        uint32_t eu = 0;
+        int mu = 0, su = 0;
+        default_ms = time_pick(none, &eu, &mu, &su);
+        if (default_ms >= 0.f) {
+            PlanPick pk;
+            pk.screen = su, pk.mode = mu, pk.entries = mu == ROAR_VISITED_LDS ? eu : 0;
+            tried.push_back(Cand{pk, default_ms, eu, mu, su});
+            if (log)
+                fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: default plan (screen %s, %s, %u tags): %.3f ms\n", L, S,
+                        su ? "on" : "off", mu == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", eu, default_ms);
+        }
+    }
+    if (!hard_error) {
+        std::vector<int> screens;
+        if (screen_free) screens = {1, 0};
+        else screens = {-1};
+        // stage 1: every screen choice with the on-chip table at 4 096 and 8 192 tags (or as the options fix it)
+        if (lds_possible) {
+            for (int sc : screens) {
+                if (entries_free) {
+                    try_pick(sc, ROAR_VISITED_LDS, 4096);
+                    if (!hard_error) try_pick(sc, ROAR_VISITED_LDS, 8192);
+                } else {
+                    try_pick(sc, mode_free ? ROAR_VISITED_LDS : -1, 0);
+                }
+                if (hard_error) break;
+            }
+        }
+        auto best_of = [&]() -> const Cand * {
+            const Cand *b = nullptr;
+            for (const Cand &c : tried)
+                if (!b || c.ms < b->ms) b = &c;
+            return b;
+        };
+        // stage 2: one step further in the direction that won (a smaller table buys resident workgroups, a bigger one forgets less)
+        if (!hard_error && entries_free) {
+            const Cand *b = best_of();
+            if (b && b->mode == ROAR_VISITED_LDS) {
+                const int sc = screen_free ? b->screen : -1;
+                if (b->entries <= 4096) try_pick(sc, ROAR_VISITED_LDS, 2048);
+                else if (b->entries >= 8192) try_pick(sc, ROAR_VISITED_LDS, 16384);
+            }
+        }
+        // stage 3: HBM epoch tags instead of the table -- only worth a look (and the tag lists' memory) once the pool is long
+        if (!hard_error && mode_free && L >= 512) {
+            const Cand *b = best_of();
+            try_pick(screen_free ? (b ? b->screen : 1) : -1, ROAR_VISITED_EXACT, 0);
+        }
+        if (!lds_possible && screen_free && !hard_error)
+            for (int sc : screens) try_pick(sc, -1, 0);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sc_ids);
+    if (hard_error) return hard_error;
+    const Cand *best = nullptr;
+    for (const Cand &c : tried)
+        if (!best || c.ms < best->ms) best = &c;
+    // the HBM tag lists (up to half of the free memory) were made for a candidate: unless it won, or they were there before, they go
+    if (!had_tags && idx->tags && !(best && best->mode == ROAR_VISITED_EXACT)) {
+        (void)hipFree(idx->tags);
+        (void)hipFree(idx->epochs);
+        idx->tags = nullptr;
+        idx->epochs = nullptr;
+        idx->slots = 0;
+        idx->last_used_tags = false;
+    }
+    if (!best) return ROAR_OK;
+    // (a win of less than 1 % over the default plan is noise: keep the default)
+    if (default_ms >= 0.f && best->ms > 0.99f * default_ms) best = &tried.front();
+    out->screen = screen_free ? best->screen : -1;
+    out->mode = mode_free ? best->mode : -1;
+    out->entries = (entries_free && best->mode == ROAR_VISITED_LDS) ? best->entries : 0;
+    *calibrated = true;
+    try {
+        roar_index::Calibration c{key, out->screen, out->mode, out->entries, best->ms, default_ms, S, L, runs};
+        idx->plan_cache.push_back(c);
+    } catch (...) {
+    }
+    if (log)
+        fprintf(stderr, "[roar calibration] L_pq=%u nq=%llu key=%llx -> screen %s, %s, %u tags: %.3f ms (default plan %.3f ms), %u launches\n", L,
+                (unsigned long long)nq, (unsigned long long)key, best->screen ? "on" : "off",
+                best->mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", best->entries, best->ms, default_ms, runs);
+    return ROAR_OK;
+}
+
+// The plan of a launch: calibrated choices where there are any (measuring them now if `qdev` is given and this kind of launch
+// has not been seen yet), defaults otherwise.  *need_queries (may be null): set when a calibration is due but qdev is null.
+int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
+                 bool *need_queries) {
+    if (need_queries) *need_queries = false;
+    idx->last_calibrated = 0;
+    if (!calibratable(idx)) return plan_search(idx, nq, k, L, plan);
+    // (argument errors come from plan_search, not from a calibration run)
+    if (!idx->base || !idx->adj || idx->gn != idx->n || L == 0 || k == 0 || k > L) return plan_search(idx, nq, k, L, plan);
+    PlanPick pick;
+    const uint64_t key = plan_key(idx, nq, L);
+    if (const roar_index::Calibration *c = find_calibration(idx, key)) {
+        pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries;
+        idx->last_calibrated = 1;
+    } else if (qdev) {
+        bool done = false;
+        int e = calibrate_plan(idx, qdev, nq, qstride, k, L, st, &pick, &done);
+        if (e) return e;
+        idx->last_calibrated = done ? 1 : 0;
+    } else if (need_queries) {
+        *need_queries = true;
+        return ROAR_OK;
+    }
+    return plan_search(idx, nq, k, L, plan, false, &pick);
+}
+}  // namespace
+
+namespace {
 // ready_dev: see RoarSearchParams::ready (the host-buffer path with a pageable query block)
 int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t L_pq,
                   uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev, uint32_t *scanned_dev,
@@ -1691,9 +1951,10 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
         return fail(ROAR_ERR_ARG, "device queries need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
     int e = use_device(idx);
     if (e) return e;
+    hipStream_t st = (hipStream_t)hip_stream;
     LaunchPlan plan;
     if (planned) plan = *planned;
-    else if ((e = plan_search(idx, nq, k, L_pq, &plan))) return e;
+    else if ((e = resolve_plan(idx, queries_dev, nq, qstride_floats, k, L_pq, st, &plan, nullptr))) return e;
     RoarSearchParams &p = plan.p;
     p.queries = queries_dev;
     p.qstride = qstride_floats;
@@ -1703,14 +1964,20 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
     p.out_hops = hops_dev;
     p.out_scanned = scanned_dev;
     p.short_count = short_count_dev;
+    // (the counting instantiation exists for the one-wave form without hub bitmap / phase timers / host gate)
+    if (idx->traffic_dev && nq <= idx->traffic_cap && !idx->building) {
+        if (ready_dev || plan.sel.form != ROAR_FORM_SEARCH || plan.sel.waves != 1 || plan.sel.prof)
+            return fail(ROAR_ERR_ARG, "traffic counters are set, but this launch (several waves per query / phase timers / pageable host "
+                                      "queries) has no counting form: option search_kernel = 1, device or pinned queries");
+        p.out_traffic = idx->traffic_dev;
+        plan.sel.stats = 1;
+    }
     if (ready_dev) {  // (search_host asked gate_allowed() first)
         if (plan.sel.form != ROAR_FORM_SEARCH || plan.sel.waves != 1 || plan.sel.hub || plan.sel.prof)
             return fail(ROAR_ERR_ARG, "internal: this kernel form cannot wait for the packing thread");
         p.ready = ready_dev;
         plan.sel.gated = 1;
     }
-    hipStream_t st = (hipStream_t)hip_stream;
-    p.counter = idx->ring + 4 * (size_t)(idx->launch_seq.fetch_add(1) % LAUNCH_RING);
     // Launches of one index on different streams may overlap (each has its own launch cell) -- except where they would
     // share per-workgroup state in HBM: the EXACT-mode tag lists / the spill lists are indexed by workgroup, so such a
     // launch waits for the previous one.
@@ -1720,12 +1987,19 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
     idx->last_used_tags = plan.sel.visited_mode == ROAR_VISITED_EXACT || p.tags != nullptr;
     const bool timed = idx->launch_events != 0 || p.tags != nullptr;  // (launches that share tag lists are ordered by ev1)
     if (timed) HIP_TRY(hipEventRecord(idx->ev0, st));
-    int rc = roar_launch_search(&p, &plan.sel, plan.grid, st);
-    if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if ((e = launch_planned(idx, plan, st))) return e;
     if (timed) {
         HIP_TRY(hipEventRecord(idx->ev1, st));
         idx->ev_valid = true;
     }
+    return ROAR_OK;
+}
+
+// the launch itself: a cell of the ring, the kernel
+int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st) {
+    plan.p.counter = idx->ring + 4 * (size_t)(idx->launch_seq.fetch_add(1) % LAUNCH_RING);
+    int rc = roar_launch_search(&plan.p, &plan.sel, plan.grid, st);
+    if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return ROAR_OK;
 }
 
@@ -1846,12 +2120,19 @@ int search_host(roar_index *idx, const float *queries, uint64_t nq, uint32_t qst
     if (deferred) {
         // the kernel forms that can wait for the packing thread: one wave per query, no hub bitmap, not instrumented
         // (the plan made here is the one the launch uses: planning can be expensive -- tag pools, hub rows)
-        if ((e = plan_search(idx, nq, k, L_pq, &probe))) return e;
-        have_plan = true;
-        const bool gate = probe.sel.form == ROAR_FORM_SEARCH && probe.sel.waves == 1 && !probe.sel.hub && !probe.sel.prof;
-        if (!gate) {  // pack in front of the launch
+        bool need_queries = false;
+        if ((e = resolve_plan(idx, nullptr, nq, qs, k, L_pq, idx->stream, &probe, &need_queries))) return e;
+        if (need_queries) {  // a launch plan calibration is due: it reads the queries, so they are packed in front of it
             pack_queries(idx, queries, nq, qstride_floats);
             deferred = false;
+        } else {
+            have_plan = true;
+            const bool gate = probe.sel.form == ROAR_FORM_SEARCH && probe.sel.waves == 1 && !probe.sel.hub && !probe.sel.prof &&
+                              !(idx->traffic_dev && nq <= idx->traffic_cap);
+            if (!gate) {  // pack in front of the launch
+                pack_queries(idx, queries, nq, qstride_floats);
+                deferred = false;
+            }
         }
     }
     uint32_t *d_ids = idx->out_dev;
@@ -1907,6 +2188,7 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
     dst->hub_mode = src->hub_mode;
     dst->profile = src->profile;
     dst->screen_mode = src->screen_mode;
+    dst->calibrate = src->calibrate;
     if ((e = alloc_base(dst, src->n))) return bail(e);
     // rows are re-strided to the padded dimension if the source adopted a wider block
     hipError_t he = hipSuccess;
@@ -2389,17 +2671,10 @@ int roar_debug_screen_keeps(roar_index *idx, const float *queries, uint64_t nq, 
     return ROAR_OK;
 }
 
-int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
-                          uint32_t *ids_dev, float *dists_dev, void *hip_stream) {
-    DeviceRestore keep_device_;
-    if (!idx || !queries_dev || !ids_dev) return fail(ROAR_ERR_ARG, "bad kNN arguments");
-    if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "exact kNN before base vectors were loaded");
-    if (k == 0 || k > 128 || k > idx->n) return fail(ROAR_ERR_ARG, "k must be in 1..min(128, n)");
-    if (qstride_floats < idx->dim_pad || (qstride_floats & 3))
-        return fail(ROAR_ERR_ARG, "device queries need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
-    if (nq == 0) return ROAR_OK;
-    int e = use_device(idx);
-    if (e) return e;
+namespace {
+// The f32 form (roar_knn.hip): every score by v_mfma_f32_32x32x2_f32.
+int exact_knn_f32(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids_dev, float *dists_dev,
+                  void *hip_stream) {
     uint32_t cap = 2048;
     while (cap < 64u * k && cap < 8192) cap <<= 1;
     const uint64_t chunk = std::min<uint64_t>(nq, 65536);
@@ -2446,6 +2721,114 @@ int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq
     }
     cleanup();
     return ROAR_OK;
+}
+
+// The bf16-screened form (roar_knn_bf16.hip): scores by v_mfma_f32_32x32x16_bf16 with a rigorous bound, the rows that can be among the
+// top k re-ranked on the f32 rows in the reference's summation order.  *done = false: not applicable here (rows too long, a norm that is
+// not finite, no memory for the bf16 copy) -- the caller runs the f32 form.
+int exact_knn_bf16(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids_dev, float *dists_dev,
+                   void *hip_stream, bool *done) {
+    *done = false;
+    if (idx->dim_pad > 512) return ROAR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint32_t KQ = roar_knn_bf16_row_quads(idx->dim_pad);
+    const uint64_t chunk = std::min<uint64_t>(nq, 65536), chunk_pad = (chunk + 255) / 256 * 256;
+    void *bb = nullptr, *bnorm = nullptr, *xmax = nullptr, *qb = nullptr, *cand = nullptr, *cursor = nullptr, *tau = nullptr, *slack = nullptr,
+         *thr = nullptr, *ovf = nullptr, *rr = nullptr;
+    auto cleanup = [&]() {
+        for (void *p_ : {bb, bnorm, xmax, qb, cand, cursor, tau, slack, thr, ovf, rr}) (void)hipFree(p_);
+    };
+    hipError_t he = roar_dev_malloc(&bb, (size_t)idx->n * KQ * 16);
+    if (he == hipSuccess) he = roar_dev_malloc(&bnorm, (size_t)idx->n * 4);
+    if (he == hipSuccess) he = roar_dev_malloc(&xmax, 4);
+    if (he == hipSuccess) he = roar_dev_malloc(&qb, (size_t)chunk_pad * KQ * 16);
+    for (void **w : {&cursor, &tau, &slack, &thr})
+        if (he == hipSuccess) he = roar_dev_malloc(w, chunk * 4);
+    if (he == hipSuccess) he = roar_dev_malloc(&ovf, 4);
+    if (he == hipSuccess) he = roar_dev_malloc(&rr, 4);
+    if (he != hipSuccess) {  // (the f32 form needs far less memory: let it try)
+        (void)hipGetLastError();
+        cleanup();
+        return ROAR_OK;
+    }
+    uint32_t xbits = 0;
+    he = hipMemsetAsync(xmax, 0, 4, st);
+    if (he == hipSuccess) he = hipMemsetAsync(rr, 0, 4, st);
+    if (he == hipSuccess)
+        he = (hipError_t)roar_knn_bf16_convert(idx->base, idx->ld, idx->dim_pad, idx->n, idx->n, bb, (float *)bnorm, (uint32_t *)xmax, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(&xbits, xmax, 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) {
+        cleanup();
+        return fail(ROAR_ERR_DEVICE, "exact kNN: bf16 copy of the base rows: %s", hipGetErrorString(he));
+    }
+    float xmax2;
+    memcpy(&xmax2, &xbits, 4);
+    if (!(xmax2 <= 1.0e36f)) {  // a row that is not finite (or whose norm overflows): no bound -- the f32 form scores everything
+        cleanup();
+        return ROAR_OK;
+    }
+    uint32_t cap = 2048;
+    while (cap < 64u * k && cap < 8192) cap <<= 1;
+    for (;;) {
+        if (roar_dev_malloc(&cand, chunk * cap * 8) != hipSuccess) {
+            cleanup();
+            return fail(ROAR_ERR_DEVICE, "out of device memory for the kNN candidate lists");
+        }
+        bool retry = false;
+        for (uint64_t q0 = 0; q0 < nq && !retry; q0 += chunk) {
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+            uint32_t overflowed = 0;
+            int rc = roar_knn_run_bf16(queries_dev + q0 * qstride_floats, qstride_floats, cnt, idx->base, idx->ld, idx->n, idx->dim_pad,
+                                       idx->ip ? 1 : 0, k, cap, bb, (const float *)bnorm, qb, cand, cursor, tau, slack, thr, ovf,
+                                       (uint32_t *)rr, ids_dev + q0 * k, dists_dev ? dists_dev + q0 * k : nullptr, &overflowed, hip_stream);
+            if (rc != 0) {
+                cleanup();
+                return fail(ROAR_ERR_DEVICE, "exact kNN (bf16 screen) kernels failed: %s", hipGetErrorString((hipError_t)rc));
+            }
+            if (overflowed) retry = true;
+        }
+        if (!retry) break;
+        (void)hipFree(cand);
+        cand = nullptr;
+        if (cap >= 16384) {  // (the selection and the re-rank keep a list in LDS: 8 bytes per entry)
+            cleanup();
+            return ROAR_OK;  // the bound admits more than fits: the f32 form
+        }
+        cap <<= 1;
+        (void)hipMemsetAsync(rr, 0, 4, st);
+    }
+    uint32_t rows = 0;
+    (void)hipMemcpy(&rows, rr, 4, hipMemcpyDeviceToHost);
+    idx->last_knn_rerank_rows = rows;
+    cleanup();
+    *done = true;
+    return ROAR_OK;
+}
+}  // namespace
+
+int roar_exact_knn_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t k,
+                          uint32_t *ids_dev, float *dists_dev, void *hip_stream) {
+    DeviceRestore keep_device_;
+    if (!idx || !queries_dev || !ids_dev) return fail(ROAR_ERR_ARG, "bad kNN arguments");
+    if (!idx->base || idx->n == 0) return fail(ROAR_ERR_ARG, "exact kNN before base vectors were loaded");
+    if (k == 0 || k > 128 || k > idx->n) return fail(ROAR_ERR_ARG, "k must be in 1..min(128, n)");
+    if (qstride_floats < idx->dim_pad || (qstride_floats & 3))
+        return fail(ROAR_ERR_ARG, "device queries need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
+    if (nq == 0) return ROAR_OK;
+    int e = use_device(idx);
+    if (e) return e;
+    idx->last_knn_bf16 = 0;
+    idx->last_knn_rerank_rows = 0;
+    if (idx->knn_mode != 1) {
+        bool done = false;
+        if ((e = exact_knn_bf16(idx, queries_dev, nq, qstride_floats, k, ids_dev, dists_dev, hip_stream, &done))) return e;
+        if (done) {
+            idx->last_knn_bf16 = 1;
+            return ROAR_OK;
+        }
+    }
+    return exact_knn_f32(idx, queries_dev, nq, qstride_floats, k, ids_dev, dists_dev, hip_stream);
 }
 
 int roar_exact_knn(roar_index *idx, const float *queries, uint64_t nq, uint32_t qstride_floats, uint32_t k, uint32_t *ids,
@@ -2566,6 +2949,15 @@ int roar_last_profile(roar_index *idx, uint64_t *out, uint64_t nq) {
     return ROAR_OK;
 }
 
+int roar_set_traffic_counters_device(roar_index *idx, uint32_t *counters_dev, uint64_t capacity_queries) {
+    if (!idx) return fail(ROAR_ERR_ARG, "bad arguments");
+    if (counters_dev && ((uintptr_t)counters_dev & 15u)) return fail(ROAR_ERR_ARG, "the counter block must be 16-byte aligned");
+    std::lock_guard<std::mutex> guard(idx->mu);
+    idx->traffic_dev = counters_dev;
+    idx->traffic_cap = counters_dev ? capacity_queries : 0;
+    return ROAR_OK;
+}
+
 int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     if (!idx || !key) return fail(ROAR_ERR_ARG, "bad arguments");
     std::string k(key);
@@ -2585,17 +2977,27 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         idx->vis_entries = (int)value;
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
+        if (idx->search_kernel != (int)value) idx->plan_cache.clear();  // (another kernel form: measured choices no longer apply)
         idx->search_kernel = (int)value;
     } else if (k == "hub_mode") {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "hub_mode must be 0 (auto), 1 (off) or 2 (on)");
+        if (idx->hub_mode != (int)value) idx->plan_cache.clear();  // (another kernel form: measured choices no longer apply)
         idx->hub_mode = (int)value;
     } else if (k == "launch_events") {
         idx->launch_events = value ? 1 : 0;
+    } else if (k == "knn_mode") {
+        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "knn_mode must be 0 (auto: bf16 screen + exact re-rank) or 1 (f32 MFMA only)");
+        idx->knn_mode = (int)value;
+    } else if (k == "calibrate") {
+        if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "calibrate must be 0 (defaults), 1 (measure, default) or 2 (forget what was measured)");
+        if (value == 2) idx->plan_cache.clear();
+        else idx->calibrate = (int)value;
     } else if (k == "screen") {
         if (value < 0 || value > 2) return fail(ROAR_ERR_ARG, "screen must be 0 (auto), 1 (off) or 2 (on)");
         idx->screen_mode = (int)value;
     } else if (k == "pool_form") {
         if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "pool_form must be 0 (auto) or 1 (LDS pool)");
+        if (idx->pool_form != (int)value) idx->plan_cache.clear();  // (another kernel form: measured choices no longer apply)
         idx->pool_form = (int)value;
     } else if (k == "profile_phases") {
         idx->profile = value ? 1 : 0;
@@ -2635,6 +3037,11 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_register_pool") *value = idx->last_sel.regpool;
     else if (k == "last_hub_bitmap") *value = idx->last_sel.hub;
     else if (k == "last_screen") *value = idx->last_screen;
+    else if (k == "last_plan_calibrated") *value = idx->last_calibrated;
+    else if (k == "last_knn_bf16") *value = idx->last_knn_bf16;
+    else if (k == "last_knn_rerank_rows") *value = idx->last_knn_rerank_rows;
+    else if (k == "calibrations") *value = (int64_t)idx->plan_cache.size();
+    else if (k == "screen_row_bytes") *value = roar_screen8_stride(idx->dim_pad);
     else if (k == "launch_events_on") *value = idx->launch_events;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;

@@ -66,6 +66,10 @@ struct RoarSearchParams {
     // per-query phase timers of the instrumented kernels (u64[nq][8]: total, select, adjacency, filter, score, merge
     // shader-clock cycles of wave 0, speculative adjacency fetches that were used, adjacency round trips paid); may be null
     unsigned long long *prof;
+    // SearchRoarGraph kernels: what each query asked the memory side for (roar_set_traffic_counters_device; may be null),
+    // u32[nq][4] = {rows scored on the 8-bit screening copy, rows scored on the f32 rows (entry point included), adjacency
+    // words fetched (whole 64-word chunks; speculative fetches that were dropped included), 0}
+    uint32_t *out_traffic;
 };
 
 // Which kernel a launch runs.
@@ -79,6 +83,7 @@ struct RoarKernelSel {
     int prof;          // SEARCH: instrumented instantiation (phase timers; Text-to-Image shape only)
     int hub;           // SEARCH: hub-bitmap form (LDS pool only)
     int gated;         // SEARCH, one wave per query, no hub / prof: queries become readable while the launch runs (RoarSearchParams::ready)
+    int stats;         // SEARCH, one wave per query, no hub / prof / gate: the instantiation that fills RoarSearchParams::out_traffic
 };
 
 struct RoarDistParams {

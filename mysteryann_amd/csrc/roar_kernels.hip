@@ -32,7 +32,8 @@ __global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchP
     u64 *rstart = reinterpret_cast<u64 *>(smem + p.off_bp);              // [64] first word of each query node's row
     uint32_t *rpre = reinterpret_cast<uint32_t *>(smem + p.off_bp + 512);  // [64] exclusive prefix of the row lengths
     const uint32_t L = p.L;
-    const uint32_t sets_mask = (1u << p.vis_sets_log2) - 1u;
+    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // (bits 30 / 31 belong to the SearchRoarGraph kernels: never set for this one)
+    const uint32_t sets_mask = (1u << sets_log2) - 1u;
     uint8_t *tags = (MODE == VIS_EXACT) ? p.tags + (u64)blockIdx.x * p.tag_stride : nullptr;
     uint32_t epoch = (MODE == VIS_EXACT) ? p.epochs[blockIdx.x] : 0u;
 
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchP
         for (uint32_t i = lane * 4; i < p.dim; i += 256)
             *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
         if (MODE == VIS_LDS) {
-            const uint32_t n16 = (4u << p.vis_sets_log2) >> 3;
+            const uint32_t n16 = (4u << sets_log2) >> 3;
             for (uint32_t i = lane; i < n16; i += 64) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
         } else {
             epoch++;
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchP
         wave_sync();
         uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
         merge_candidates(pool, ck, p.n_init, L, psize, cur, lane);  // ck[0] again: dropped as a duplicate
-        (void)visited_filter<MODE>(isinit, iid, vis, sets_mask, p.vis_sets_log2, tags, epoch);
+        (void)visited_filter<MODE>(isinit, iid, vis, sets_mask, sets_log2, tags, epoch);
         wave_sync();
 
         while (cur < psize) {
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(64, 3) roar_bipartite_kernel(const RoarSearchP
                         if (rpre[own + step] <= c) own += step;
                     uint32_t nb = 0;
                     if (has) nb = p.bp_nbrs[rstart[own] + (c - rpre[own])];
-                    bool fresh = visited_filter<MODE>(has, nb, vis, sets_mask, p.vis_sets_log2, tags, epoch);
+                    bool fresh = visited_filter<MODE>(has, nb, vis, sets_mask, sets_log2, tags, epoch);
                     // the same node twice in this chunk: the later lane is the repeat (:331-334)
                     for (u64 it = __ballot(fresh); it;) {
                         const int j = __ffsll((long long)it) - 1;

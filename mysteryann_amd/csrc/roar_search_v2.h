@@ -559,7 +559,11 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ctrl words (LDS) of the multi-wave forms: 0 query, 1 candidates of the round trip (NONE = query finished),
 // 2 survivors appended by the waves, 3 pool full, 4-5 reject threshold (register-pool form)
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false>
+// STATS: the instantiation that also counts what a query asks the memory side for (RoarSearchParams::out_traffic) -- the same
+// hop, plus one LDS add of lane 0 where something is fetched.  Its own instantiation because the kernels of the benchmark
+// shapes sit exactly at their register budget (the counting costs the one-wave 200-d kernel 12 bytes of scratch inside the hop);
+// what a query fetches does not depend on timing, so the counts are those of the plain kernel on the same launch plan.
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false, bool STATS = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
@@ -690,6 +694,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         // cursor `cur` = index of the closest unexpanded entry.
         u64 pk = ~0ull;
         uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
+        // what the query asks the memory side for, beside cmps (RoarSearchParams::out_traffic): one packed LDS word, ctrl[12..13] =
+        // rows scored on the 8-bit copy | rows that passed it << 24 | 64-word adjacency chunks fetched << 44 -- one LDS add of
+        // lane 0 where something is fetched, no register lives through the hop for it
+        u64 *const traffic = reinterpret_cast<u64 *>(const_cast<uint32_t *>(ctrl + 12));
+        auto count_traffic = [&](u64 v) {
+            if constexpr (STATS)
+                if (lane == 0) atomicAdd(traffic, v);
+        };
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
         uint32_t nhub = 0;  // HUB: hub neighbours of the current row (they come first)
         const uint32_t *arow = ADJ;
@@ -706,7 +718,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
             pf = p.ep;
             // entry point: scored, inserted, NOT marked visited (index_bipartite.cpp:2337-2353)
-            if (lane == 0) cid[0] = p.ep;
+            if (lane == 0) {
+                cid[0] = p.ep;
+                if constexpr (STATS) *traffic = (u64)(HUB ? (AS > 128u ? 4u : 3u) : 1u) << 44;
+            }
             wave_sync();
             uint32_t one = 0;
             score_rows<IP, NCH, TAIL, 1, false>(p.base, p.ld, p.dim, lq, cid, ck, 1, ~0ull, &one, lane);
@@ -778,6 +793,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (AS > 128u) a2 = arow[128 + lane];
                                 a3 = arow[192 + lane];
                             }
+                            count_traffic((u64)(HUB ? (AS > 128u ? 4u : 3u) : 1u) << 44);
                             if (PROF) n_rt++;
                         } else if (PROF) {
                             pf_hit++;
@@ -789,6 +805,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         } else if (deg > 63u) {  // a long row: its other chunks (a second round trip, rare on a sparse graph)
                             a1 = arow[64 + lane];
                             if (deg > 127u) a2 = arow[128 + lane];
+                            count_traffic((u64)(deg > 127u ? 2u : 1u) << 44);
                         }
                         scanned += deg;
                         wpos = 0;
@@ -880,6 +897,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             if (AS > 128u) a2 = nrow[128 + lane];
                         }
                         if (HUB) a3 = nrow[192 + lane];
+                        count_traffic((u64)(1u + (whole ? (AS > 128u ? 2u : 1u) : 0u) + (HUB ? 1u : 0u)) << 44);
                     }
                     if constexpr (SD > 0) {  // 8-bit screen (see screen8_pass), once the pool is full
                         if (psize == L && m > 4) {
@@ -892,8 +910,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             if (scr) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
+                                [[maybe_unused]] const uint32_t coded = m;
                                 m = screen8_rows<SD, IP>(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]),
                                                          __uint_as_float(ctrl[10]), lane);
+                                count_traffic((u64)coded | ((u64)m << 24));
                             }
                         }
                     }
@@ -984,6 +1004,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 if (o_cmps) o_cmps[q] = cmps;
                 if (o_hops) o_hops[q] = hops;
                 if (o_scanned) o_scanned[q] = scanned;
+                if constexpr (STATS) {
+                    uint32_t *const o_traffic = *const_cast<uint32_t *const volatile *>(&ka->out_traffic);
+                    const u64 t = *traffic;
+                    const uint32_t coded = (uint32_t)t & 0xFFFFFFu, passed = (uint32_t)(t >> 24) & 0xFFFFFu;
+                    // every neighbour counted in cmps was scored on the f32 rows, but for those the screen dropped; + the entry point
+                    *reinterpret_cast<uint4 *>(o_traffic + 4 * (u64)q) = make_uint4(coded, 1u + cmps - coded + passed, (uint32_t)(t >> 44) * 64u, 0u);
+                }
                 if (psize < p.k) atomicAdd(*const_cast<uint32_t *const volatile *>(&ka->counter) + 2, 1u);  // short queries of this launch
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
@@ -1043,10 +1070,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #ifndef ROAR_WPE_512
 #define ROAR_WPE_512 2
 #endif
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false, bool STATS = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(NCH > 16 ? ROAR_WPE_512 : 3, NCH > 16 ? ROAR_WPE_512 : 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED, STATS>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -1066,6 +1093,12 @@ const void *pick_form(const RoarKernelSel &s) {
                       : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
         else
             return nullptr;
+    }
+    if (s.stats) {  // one wave per query, counting what each query fetches (RoarSearchParams::out_traffic)
+        if (s.prof || s.waves != 1 || s.gated || (s.hub && rp)) return nullptr;
+        if (s.hub) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, true, false, true>;
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, false, true>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, true>;
     }
     if (s.gated) {  // one wave per query, waiting for the host's rows-written counter (pageable host query blocks)
         if (s.hub || s.prof || s.waves != 1) return nullptr;

@@ -172,6 +172,17 @@ class IndexBipartite:
         capi.check(self._lib.roar_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
 
+    def SetTrafficCounters(self, block):
+        """roar_set_traffic_counters_device: `block` = int32 CUDA tensor [capacity, 4] (or None to switch it off); launches of at
+        most `capacity` queries then write {rows on the 8-bit copy, rows on the f32 rows, adjacency words fetched, 0} per query."""
+        if block is None:
+            capi.check(self._lib.roar_set_traffic_counters_device(self._h, None, 0))
+            self._traffic = None
+            return
+        assert block.is_cuda and block.is_contiguous() and block.shape[1] == 4 and block.element_size() == 4
+        capi.check(self._lib.roar_set_traffic_counters_device(self._h, C.c_void_p(block.data_ptr()), block.shape[0]))
+        self._traffic = block  # (keeps the tensor alive while the index writes to it)
+
     def LastProfile(self, nq):
         """Phase timers of the most recent instrumented launch (option profile_phases): uint64 [nq, 16]
         (layout: roar_last_profile in include/roargraph_amd.h)."""

@@ -7,6 +7,11 @@ distribution shift (out-of-distribution queries, as in cross-modal data):
               query q = (1.5 z' + 0.5) B + 0.1 eps,  B = A + 0.5 Delta, scaled so |ip| <~ 1
   SIFT shape  |N(0,1)| * 40 rounded and clipped to 0..255, D = 128, L2 (prepare_data.sh ranges)
   WebVid shape unit-norm rows (prepare_for_clip_webvid.py:92-98), D = 512, IP / cosine
+  T2I-hard    the T2I shape WITHOUT the low-rank structure the 8-bit screen profits from: base x = mu + sigma eps with
+              eps ~ N(0, I_D) (latent = D: isotropic, query-base scores tightly bunched), the same row norm as the T2I set
+              on average; `offset` > 0 adds a common component mu of |mu| = offset x the isotropic part's norm (embedding
+              sets sit in a narrow cone: most of a score is then the same for every row, and a bound in units of |q||x|
+              says little); queries q = 0.5 u + 1.5 sigma_q eps' around another direction u (out of distribution)
 
 `numpy` versions make the small fixtures; `torch` versions generate the full-size sets directly
 in HBM on the GPU box (torch is plumbing here: RNG + device memory).
@@ -90,6 +95,57 @@ def t2i_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, 
             z = 1.5 * torch.randn((mm, LATENT), generator=g, device=device) + 0.5
             e = torch.randn((mm, d), generator=g, device=device)
             out[i:i + mm] = z @ B + (0.1 * float(s)) * e
+        return out
+
+    q = queries(nq, seed + 2 if query_seed is None else query_seed)
+    learn = queries(n_learn, seed + 3) if n_learn else None
+    return base, q, learn
+
+
+def _hard_maps(d, seed, offset):
+    rng = np.random.default_rng(seed + 77)
+    _, _, s = _maps(d, seed)
+    sigma = np.float32(np.sqrt(LATENT) * s)  # the T2I set's per-component scale: |x|^2 ~ LATENT d s^2
+    u = rng.standard_normal(d).astype(np.float32)
+    u *= np.float32(np.sqrt(d)) * sigma / np.linalg.norm(u)  # |u| = the isotropic part's expected norm
+    v = rng.standard_normal(d).astype(np.float32)
+    v *= np.float32(np.sqrt(d)) * sigma / np.linalg.norm(v)
+    return sigma, (np.float32(offset) * u).astype(np.float32), v
+
+
+def t2i_hard_numpy(n, nq, d=200, seed=1234, n_learn=0, offset=0.0):
+    sigma, mu, v = _hard_maps(d, seed, offset)
+    rng = np.random.default_rng(seed + 1)
+    base = (mu + sigma * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+
+    def queries(m, r):
+        return (np.float32(0.5) * v + np.float32(1.5) * sigma * r.standard_normal((m, d)).astype(np.float32)).astype(np.float32)
+
+    q = queries(nq, np.random.default_rng(seed + 2))
+    learn = queries(n_learn, np.random.default_rng(seed + 3)) if n_learn else None
+    return base, q, learn
+
+
+def t2i_hard_torch(n, nq, d=200, seed=1234, n_learn=0, device="cuda", chunk=1 << 20, query_seed=None, offset=0.0):
+    """Full-size T2I-hard set generated in HBM (see the module docstring).  -> (base [n, d], queries [nq, d], learn|None)."""
+    import torch
+
+    sigma, mu, v = _hard_maps(d, seed, offset)
+    mu = torch.from_numpy(mu).to(device)
+    v = torch.from_numpy(v).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1)
+    base = torch.empty((n, d), dtype=torch.float32, device=device)
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        base[i:i + m] = mu + float(sigma) * torch.randn((m, d), generator=g, device=device)
+
+    def queries(m, sd):
+        g.manual_seed(sd)
+        out = torch.empty((m, d), dtype=torch.float32, device=device)
+        for i in range(0, m, chunk):
+            mm = min(chunk, m - i)
+            out[i:i + mm] = 0.5 * v + (1.5 * float(sigma)) * torch.randn((mm, d), generator=g, device=device)
         return out
 
     q = queries(nq, seed + 2 if query_seed is None else query_seed)

@@ -84,3 +84,31 @@ def test_plain_multi_gpu_command_runs_end_to_end_without_a_gpu():
     assert r.returncode != 0
     assert "torch.distributed.run" in r.stderr and "needs an MI355X" in r.stderr
     assert "WORLD_SIZE is" not in r.stderr
+
+
+def test_implemented_bytes_formula():
+    """roofline.bytes_per_launch: screen rows + f32 rows + adjacency words + query read + result write."""
+    import bench
+
+    # 10 queries, 200-d padded, 256-byte screen rows, k = 10: 1000 coded rows, 150 f32 rows, 6400 adjacency words
+    got = bench.implemented_bytes(1000, 150, 6400, 10, 200, 256, 10)
+    assert got == 256 * 1000 + 800 * 150 + 4 * 6400 + (800 + 80) * 10
+    # screen off: nothing coded, the reference's 4 D per distance evaluation
+    assert bench.implemented_bytes(0, 2840, 0, 1, 200, 256, 10) == 800 * 2840 + 880
+
+
+def test_kernel_trace_span_of_overlapping_launches(tmp_path):
+    import bench
+
+    search = "void (anonymous namespace)::roar_search_v2_kernel<1, true, 12, true, 1, true, false, false, false, false>(RoarSearchParams)"
+    p = tmp_path / "x_kernel_trace.csv"
+    with open(p, "w") as f:
+        f.write("Kind,Agent_Id,Queue_Id,Kernel_Name,Start_Timestamp,End_Timestamp\n")
+        f.write(f'KERNEL_DISPATCH,1,1,"knn_pass_kernel",0,100\n')
+        f.write(f'KERNEL_DISPATCH,1,1,"{search}",1000,2000\n')  # warm-up, outside the last four
+        for i in range(4):  # four launches overlapping two at a time: 3 ms each, started 1.5 ms apart
+            f.write(f'KERNEL_DISPATCH,1,{i % 2},"{search}",{10_000_000 + 1_500_000 * i},{13_000_000 + 1_500_000 * i}\n')
+    span, mean = bench.kernel_trace_span(str(p), 4)
+    assert span == pytest.approx(7.5) and mean == pytest.approx(3.0)
+    with pytest.raises(RuntimeError):
+        bench.kernel_trace_span(str(p), 6)

@@ -78,11 +78,11 @@ def brute_force_gt(torch, base, d, queries, k, chunk_rows=1 << 20, chunk_q=2048,
 def build_reference_graph(torch, mi, idx, learn, n_exact, stage2_L, say=log):
     """The benchmark's index: the reference's BuildRoarGraph (canonical parameters M_sq = 100, M_pjbp = 35, L_pjpq = 500,
     run_roargraph_test.sh:9) on learn->base lists of ALL of `learn` (the reference's own T2I-10M run has as many training
-    queries as base points).  Exact lists (f32 MFMA brute force) cost 50 s per million training queries, so only the first
-    n_exact of them get exact lists; those make a first graph, the lists of the others are SEARCHED on it (k = 100,
-    L_pq = stage2_L: seconds for 8 M queries), and the final graph is built from all lists by the same BuildRoarGraph.
-    T2I-10M, 2 M exact + 8 M searched at L_pq = 200 / 400 / 600 / 1 000: recall@10 at L_pq = 50 0.8994 / 0.9004 / 0.9011 /
-    0.9007 (10 M exact lists, 501 s: 0.9005; 2 M exact lists alone: 0.8954).  -> description"""
+    queries as base points).  Round 4: every list is EXACT (n_exact = all: the bf16-screened generator makes 10 M lists in ~75 s;
+    rounds 1-3's f32 MFMA form needed 500 s).  With n_exact < len(learn) -- round 3's default, kept as an option -- only the
+    first n_exact queries get exact lists; those make a first graph, the lists of the others are SEARCHED on it (k = 100,
+    L_pq = stage2_L), and the final graph is built from all lists by the same BuildRoarGraph (T2I-10M, 2 M exact + 8 M
+    searched at L_pq = 600: recall@10 at L_pq = 50 0.9011; 10 M exact lists: 0.9005).  -> description"""
     import time as _t
 
     n_learn = learn.shape[0]
@@ -90,7 +90,8 @@ def build_reference_graph(torch, mi, idx, learn, n_exact, stage2_L, say=log):
     t0 = _t.time()
     lists, _ = idx.ExactKnnDevice(learn[:n_exact], 100, want_dists=False)
     torch.cuda.synchronize()
-    say(f"exact learn->base kNN ({n_exact} x 100, MFMA generator) in {_t.time() - t0:.1f}s")
+    say(f"exact learn->base kNN ({n_exact} x 100, {'bf16 MFMA screen + exact f32 re-rank' if idx.info('last_knn_bf16') else 'f32 MFMA'}) "
+        f"in {_t.time() - t0:.1f}s")
     p = mi.Parameters()
     p.Set("M_sq", 100), p.Set("M_pjbp", 35), p.Set("L_pjpq", 500)
     idx.BuildRoarGraphDevice(lists, p)
@@ -118,6 +119,17 @@ def implemented_bytes(rows_code, rows_f32, adj_words, queries, dim_padded, scree
     row this kernel reads; visited-set traffic is excluded there and here."""
     return (float(screen_row_bytes) * float(rows_code) + 4.0 * dim_padded * float(rows_f32) + 4.0 * float(adj_words)
             + (4.0 * dim_padded + 8.0 * k) * float(queries))
+
+
+def share_of_8_block(nq, steps, wall_share, wall_share_serial, depth, cap, value_this_run):
+    """config.emulated_share_of_8: what the strong-scaling run at N = 8 asks of each rank -- nq / 8 queries per step -- timed on THIS GPU
+    over the same K steps (wall seconds with `depth` launches in flight / one at a time).  The eight ranks run side by side, so the
+    projected whole-job rate is nq x K / that wall time; its ratio to this run's own value is the projected speed-up."""
+    return {"queries_per_launch": nq // 8, "launches_in_flight": depth, "workgroups_per_launch_cap": cap,
+            "ms_per_step": wall_share * 1e3 / steps, "ms_per_step_one_launch_at_a_time": wall_share_serial * 1e3 / steps,
+            "projected_value_8_gpus": nq * steps / wall_share,
+            "projected_speedup_over_this_run": (nq * steps / wall_share) / value_this_run,
+            "note": "a projection from ONE GPU: the first nq / 8 rows of every batch on this GPU stand for one of eight ranks"}
 
 
 def kernel_trace_span(csv_path, steps, name="roar_search_v2_kernel"):
@@ -233,8 +245,8 @@ def parse_args(argv=None):
                          "learn->base lists with its canonical parameters M_sq 100 / M_pjbp 35 / L_pjpq 500 "
                          "(run_roargraph_test.sh:9); bootstrap = roar_build_graph (no exact lists needed)")
     ap.add_argument("--ref-learn", type=int, default=0,
-                    help="--builder reference: training queries whose exact top-100 lists are computed (0 = n / 5; T2I-10M: "
-                         "1 M / 2 M / 4 M lists -> recall 0.903 / 0.908 / 0.911 at L_pq 55, 50 / 100 / 200 s of f32 MFMA)")
+                    help="--builder reference: training queries whose exact top-100 lists are computed (0 = all of them for the t2i "
+                         "workload -- the reference's own input; n / 5 for the other shapes).  Fewer + --ref-learn2: round 3's two-stage lists")
     ap.add_argument("--ref-learn2", type=int, default=-1,
                     help="--builder reference, second stage: this many training queries in all (-1 = default: as many as base points, the "
                          "reference's own T2I-10M setting, for the t2i workload; 0 for the others = no second stage).  The first --ref-learn of them get exact lists (MFMA brute force) and make a first "
@@ -259,6 +271,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the profiled child of measure_traffic()
+    ap.add_argument("--plan", default="", help=argparse.SUPPRESS)  # --pmc-child: the launch plan the parent's calibration picked (screen,mode,tags)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-share-probe", action="store_true",
                     help="N = 1: skip the emulated share of 8 (the timed loop once more over the first nq / 8 rows of every batch)")
@@ -314,14 +327,10 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     dev = torch.device("cuda", local)
-    ranks_seen = 1
-    if use_dist:  # a one-element all-reduce of ones over RCCL: how many ranks the collective really spans
-        t_ = torch.ones(1, device=dev, dtype=torch.int32)
-        dist.all_reduce(t_)
-        ranks_seen = int(t_.item())
-
     from mysteryann_amd import index as mi
     from mysteryann_amd import parallel, synth
+
+    ranks_seen = parallel.ranks_seen(dev)  # a one-element all-reduce of ones over RCCL: how many ranks the collective really spans
 
     if args.sharded:
         run_sharded(args, np, torch, mi, synth, dev, rank, world, use_dist)
@@ -335,7 +344,9 @@ def main():
     n_learn = args.learn if args.learn >= 0 else args.n
     n_exact = 0
     if args.builder == "reference":
-        n_exact = args.ref_learn or args.n // 5
+        # exact lists of ALL training queries for the t2i workload (as many as base points: the reference's own T2I-10M setting,
+        # run_roargraph_test.sh:5-9; 75 s with the bf16-screened generator), of n / 5 for the other shapes
+        n_exact = args.ref_learn or (args.n if args.workload == "t2i" else args.n // 5)
         stage2 = args.ref_learn2 if args.ref_learn2 >= 0 else (args.n if args.workload == "t2i" else 0)
         n_learn = max(n_exact, stage2)
     gen = {"t2i": synth.t2i_torch, "webvid": synth.webvid_torch, "sift": synth.sift_torch,
@@ -397,6 +408,11 @@ def main():
         idx.set_option("screen", 1 if args.no_screen else 0)
         if args.vis_entries:
             idx.set_option("vis_entries", args.vis_entries)
+        if args.plan:  # the plan the parent measured and timed: the same launches here, whatever this process would have measured
+            scr_, mode_, tags_ = (int(v_) for v_ in args.plan.split(","))
+            idx.set_option("screen", 2 if scr_ else 1)
+            idx.set_option("visited_mode", mode_)
+            idx.set_option("vis_entries", tags_)
         # the timed loop's launches in the regime asked for: one after the other, or --in-flight launches overlapping on as many
         # streams with the workgroup cap of the timed loop (a --pmc pass serialises dispatches: what it measures is the capped
         # launch's traffic; a --kernel-trace pass lets them overlap and records every launch's start and end)
@@ -631,11 +647,7 @@ def main():
         idx.set_option("max_grid", 0)
         wall_s8_1, _ = timed(lambda s_: s_ % B)
         batches, outs = keep_b, keep_o
-        share8 = {"queries_per_launch": sh, "launches_in_flight": depth, "workgroups_per_launch_cap": share_grid if depth > 1 else 0,
-                  "ms_per_step": wall_s8 * 1e3 / args.steps, "ms_per_step_one_launch_at_a_time": wall_s8_1 * 1e3 / args.steps,
-                  "projected_value_8_gpus": args.nq * args.steps / wall_s8,
-                  "projected_speedup_over_this_run": (args.nq * args.steps / wall_s8) / qps,
-                  "note": "a projection from ONE GPU: the first nq / 8 rows of every batch on this GPU stand for one of eight ranks"}
+        share8 = share_of_8_block(args.nq, args.steps, wall_s8, wall_s8_1, depth, share_grid if depth > 1 else 0, qps)
 
     ref_bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
     bytes_per_launch = float(np.mean([impl_bytes[s_ % B] for s_ in range(args.steps)]))
@@ -817,11 +829,14 @@ def measure_traffic(args, idx, L, nq_launch, depth=1, pipe_grid=0):
         os.close(fd)
         idx.SaveProjectionGraph(cache)
     steps = 8
+    # the launch plan of the timed loop (what the calibration picked in THIS process): screen on / off, visited form, tags
+    vm = idx.info("last_visited_mode")
+    plan = f"{idx.info('last_screen')},{0 if vm == 0 else (3 if idx.info('last_visited_forgetful') else 1)},{idx.info('last_vis_entries') if vm != 0 else 0}"
     child0 = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--graph-cache", cache, "--L", str(L), "--workload", args.workload,
               "--n", str(args.n), "--dim", str(args.dim), "--nq", str(args.nq), "--batches", str(args.batches), "--k", str(args.k),
               "--seed", str(args.seed), "--visited", args.visited, "--vis-entries", str(args.vis_entries), "--steps", str(steps),
               "--warmup", "1", "--builder", args.builder, "--learn", "0", "--ref-learn", "1", "--ref-learn2", "0",
-              "--hard-offset", str(args.hard_offset)] + (["--no-screen"] if args.no_screen else [])
+              "--hard-offset", str(args.hard_offset), "--plan", plan] + (["--no-screen"] if args.no_screen else [])
     env = dict(os.environ, TMPDIR="/tmp")
     L2SET = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum")
 

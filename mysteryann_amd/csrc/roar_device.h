@@ -13,6 +13,8 @@ struct RoarSearchParams {
     // screen8i_pass / screen8_pass); null = off.  With it the LDS block at off_q holds the query's own 8-bit codes (dim
     // bytes) behind its dim floats
     const unsigned char *screen;
+    // inner product: the centre of the screening copy's codes (they code x - mu; dim floats), null = not centred
+    const float *screen_mu;
     // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
     const uint32_t *adj;
     uint32_t adj_stride;
@@ -124,14 +126,15 @@ int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint
 // f32 rows of dim floats (dim % 8 == 0, dim <= 1024) at stride ld -> screening rows (see RoarSearchParams::screen);
 // out: n x roar_screen8_stride(dim) bytes
 // l2 != 0: the L2 form of the row (dim % 16 == 0): dim codes u_i with x~_i = lo + s u_i, then s, lo, |x~|^2, bound
-int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, void *stream);
+// mu (inner-product form only; may be null): dim floats the codes are centred on
+int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream);
 int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
 // tests: the search's own screening passes over explicit (query, row) pairs, every row against its own threshold (roar_search_v2.h,
 // roar_screen_check_kernel); _1 = inner product, _0 = L2
-int roar_launch_screen_check_1(const unsigned char *scr, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq, const uint32_t *ids,
-                               float *chk, uint32_t m, void *stream);
-int roar_launch_screen_check_0(const unsigned char *scr, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq, const uint32_t *ids,
-                               float *chk, uint32_t m, void *stream);
+int roar_launch_screen_check_1(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
+                               const uint32_t *ids, float *chk, uint32_t m, void *stream);
+int roar_launch_screen_check_0(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
+                               const uint32_t *ids, float *chk, uint32_t m, void *stream);
 // Max resident workgroups per CU for the selected kernel at this LDS size.
 int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
 #ifdef __cplusplus

@@ -414,7 +414,7 @@ __device__ __forceinline__ uint32_t bf16_up(float v) {  // v >= 0 or +inf: the s
 }
 
 __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
-                                                                uint32_t stride) {
+                                                                uint32_t stride, const float *__restrict__ mu) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (v >= n) return;
@@ -426,7 +426,13 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (64 * j + lane < nf4) a[j] = row[64 * j + lane];
+        if (64 * j + lane < nf4) {
+            a[j] = row[64 * j + lane];
+            if (mu) {  // the codes are those of y = x - mu (f32 subtraction: its rounding, <= 2^-24 |y_i|, is paid for in B below)
+                const float4 u = reinterpret_cast<const float4 *>(mu)[64 * j + lane];
+                a[j].x -= u.x, a[j].y -= u.y, a[j].z -= u.z, a[j].w -= u.w;
+            }
+        }
         mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[j].x), __builtin_fabsf(a[j].y)),
                                                   __builtin_fmaxf(__builtin_fabsf(a[j].z), __builtin_fabsf(a[j].w))));
         bad |= (a[j].x != a[j].x) | (a[j].y != a[j].y) | (a[j].z != a[j].z) | (a[j].w != a[j].w);  // (fmaxf drops NaNs: test the components)
@@ -460,10 +466,11 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
         c2 += __shfl_xor(c2, o, 64);
     }
     const uint32_t meta = (dim / 16u) * 4u + 2u;  // the last two words of the chunk after the full ones
-    // N: |s c| rounded up.  B: |x - s c| rounded up (1.001: the f32 evaluation of e2), + 2^-23 N: each d_i was measured against the ROUNDED
-    // product s c_i, the kernel means the real one
+    // N: |s c| rounded up.  B: |y - s c| rounded up (1.001: the f32 evaluation of e2), + 2^-23 N: each d_i was measured against the ROUNDED
+    // product s c_i, the kernel means the real one; + 2^-23 N more when the codes are centred: y_i here is the f32 difference x_i - mu_i, the
+    // bound is about the real one (|fl(y) - y| <= 2^-24 |y|, |y| <= N + B)
     const float nrm = sc * __builtin_sqrtf(c2) * 1.0001f;
-    const float bnd = 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 1.2e-7f * nrm;
+    const float bnd = 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 2.4e-7f * nrm;
     if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
     if (lane == 1) o32[meta + 1] = anybad ? 0x7F80u : (bf16_up(bnd) | (bf16_up(nrm) << 16));
     for (uint32_t w = nf4 + lane; w < stride / 4; w += 64)  // zeros between the codes and the meta words, and after them
@@ -741,7 +748,7 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
     return (int)hipGetLastError();
 }
 
-extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, void *stream) {
+extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream) {
     if (n == 0) return 0;
     if (dim % 8 || dim > 1024 || (l2 && dim % 16)) return (int)hipErrorInvalidValue;
     if (l2) {
@@ -750,7 +757,7 @@ extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
-                       roar_screen8_stride(dim));
+                       roar_screen8_stride(dim), mu);
     return (int)hipGetLastError();
 }
 

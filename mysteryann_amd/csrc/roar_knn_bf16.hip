@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "roar_wave.h"
 
@@ -117,10 +118,42 @@ __device__ __forceinline__ float knn_eps(float ea, float kq, float bn, float kap
     return ip ? ea * xn : __builtin_fmaf(ea, xn, __builtin_fmaf(kappa, bn, kq));
 }
 
+// LDS accesses of the pass kernel's main loop are written as instructions: the compiler cannot tell that a ds_read does not touch the
+// buffer an LDS-DMA in flight is writing (one LDS array, run-time buffer index) and would wait vmcnt(0) in front of every one of them --
+// draining the look-ahead loads the pipeline lives on.  The waits these need (lgkmcnt) are written out with them.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read2_b128(uint32_t a0, uint32_t a1, u32x4 &f0, u32x4 &f1) {
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(f0), "=&v"(f1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
+}
+template <int LEFT>  // wait until at most LEFT LDS instructions of this wave are outstanding; the fragments become usable here
+__device__ __forceinline__ void lds_wait(u32x4 &f0, u32x4 &f1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(LEFT) : "memory");
+}
+__device__ __forceinline__ void lds_read2_f32(uint32_t a, float &x0, float &x1) {  // a[0], a[32]
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t a, uint32_t v) {
+    uint32_t old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(a), "v"(v) : "memory");
+    return old;
+}
+__device__ __forceinline__ void lds_write_b64(uint32_t a, u64 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write_b16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct KnnBfParams {
     const uint4 *qb;  // [nq padded to QT][KQ]
     const uint4 *bb;  // [n][KQ]
-    uint32_t KQ, ksteps;
+    uint32_t KQ;
     uint32_t nq;
     u64 first, stride, count;  // rows first + i * stride, i < count
     uint32_t rows_per_slice;   // multiple of BT
@@ -134,29 +167,40 @@ struct KnnBfParams {
     int ip;
 };
 
-// KS = K steps of 16 the A fragments are sized for (dim <= 16 KS); p.ksteps <= KS are real, the others are skipped
-template <int KS>
+// KS = K steps of 16 the A fragments are sized for (dim <= 16 KS; p.ksteps <= KS are real, the others are skipped); JT = LDS-DMA
+// instructions per thread and tile for the longest row of that bucket; NBUF = tile buffers (NBUF - 1 tiles in flight).
+//
+// Pipeline (one iteration = one tile of 64 base rows): a COUNTED wait -- s_waitcnt vmcnt((NBUF - 2)(JT + 1)): this thread's loads of the
+// tile about to be read have landed, those of the NBUF - 2 tiles behind it stay in flight -- then a raw s_barrier (everybody's have, and
+// everybody has left the buffer read last), the loads of tile t + NBUF - 1 into that buffer, the MFMAs, the epilogue.  A
+// __syncthreads() would drain every load in flight (the compiler's fence waits vmcnt(0) for a pending LDS write), and one tile ahead
+// is not enough: a tile is ~0.35 us of MFMA work, a load from the L2 / Infinity Cache ~1-2 us away (first form of this kernel: 267
+// TFLOP/s).  For the count to be the same in every wave each thread issues exactly JT + 1 loads per tile (slots past the tile and tiles
+// past the slice re-read a valid row into spare LDS), the rows' squared norms travel by LDS-DMA too, and nothing else in the loop is a
+// vector-memory operation: admitted rows are staged in LDS (ds_add_rtn + ds_write) and leave for the candidate lists every 32 tiles.
+template <int KS, int JT, int NBUF, int HCAP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) knn_pass_bf16_kernel(const KnnBfParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const uint32_t KQ = p.KQ;
-    const uint32_t tile_quads = BT * KQ, J = (tile_quads + 511u) / 512u;  // DMA instructions per thread and tile
-    uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + (size_t)J * 512;
+    uint4 *bufs = reinterpret_cast<uint4 *>(smem);                                       // [NBUF][JT * 512] quads
+    float *nrm = reinterpret_cast<float *>(smem + (size_t)NBUF * JT * 512 * 16);          // [NBUF][64] squared norms of the tile's rows
+    u64 *skey = reinterpret_cast<u64 *>(smem + (size_t)NBUF * JT * 512 * 16 + NBUF * 256);  // [HCAP] bits(d^) << 32 | row
+    uint16_t *sql = reinterpret_cast<uint16_t *>(skey + HCAP);                            // [HCAP] query of the entry, relative to q0
+    uint32_t *scnt = reinterpret_cast<uint32_t *>(sql + HCAP);
     const uint32_t nqt = (p.nq + QT - 1) / QT;
     const uint32_t q0 = (blockIdx.x % nqt) * QT;
     const u64 s0 = (u64)(blockIdx.x / nqt) * p.rows_per_slice;
     const u64 s1 = std::min<u64>(p.count, s0 + p.rows_per_slice);
+    if (s0 >= s1) return;
+    if (tid == 0) *scnt = 0;
 
     // A fragments: query row q0 + 32 wave + r, k = 16 ks + 8 h .. + 7  (the copy is padded to whole tiles with zero rows)
     bf16x8 af[KS];
     {
         const uint4 *qrow = p.qb + (u64)(q0 + 32 * wave + r) * KQ + h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((uint32_t)ks < p.ksteps) v = qrow[2 * ks];
-            af[ks] = __builtin_bit_cast(bf16x8, v);
-        }
+        for (int ks = 0; ks < KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, qrow[2 * ks]);  // (rows are zero beyond the dimension)
     }
     // this lane's 16 query rows (D row = (reg & 3) + 8 (reg >> 2) + 4 h): admission bound U (+ the query's constant part of eps) and
     // the query's factor of the row-dependent part
@@ -167,52 +211,91 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         thr[g] = qi < p.nq ? p.U[qi] + p.kq[qi] : -__builtin_inff();
         eq[g] = qi < p.nq ? p.ea[qi] : 0.f;
     }
-    // where this thread's DMA slots of a tile come from: slot = j * 512 + tid -> (row of the tile, quad of the row)
-    uint32_t srow[9], scq[9];  // J <= 9 (KQ <= 65)
+    // where this thread's DMA slots of a tile come from: slot = j * 512 + tid -> (row of the tile, quad of the row); slots past the tile
+    // re-read its last row (into the spare end of the buffer)
+    uint32_t srow[JT], scq[JT];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < JT; ++j) {
         const uint32_t slot = (uint32_t)j * 512u + (uint32_t)tid;
-        srow[j] = slot / KQ;
+        srow[j] = std::min<uint32_t>(slot / KQ, BT - 1);
         scq[j] = slot % KQ;
     }
-    auto dma = [&](uint4 *buf, u64 t0) {
+    // everything loaded so far is in its registers before the pipeline starts: inside the loop the only vector-memory operations are the
+    // LDS-DMA loads, and the compiler has no reason to wait for anything there (it would wait for ALL of them)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            if ((uint32_t)j < J && srow[j] < (uint32_t)BT) {
-                u64 si = t0 + srow[j];
-                si = si < p.count ? si : p.count - 1;  // (a tile past the end re-reads the last row: masked in the epilogue)
-                const uint4 *src = p.bb + (p.first + si * p.stride) * KQ + scq[j];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(buf + (size_t)j * 512 + wave * 64), 16, 0, 0);
-            }
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(af[ks]));
+#pragma unroll
+    for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(thr[g]), "v"(eq[g]));
+    auto dma = [&](uint32_t b, u64 t0) {  // JT + 1 loads, always
+        uint4 *buf = bufs + (size_t)b * JT * 512;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            u64 si = t0 + srow[j];
+            si = si < p.count ? si : p.count - 1;  // (rows past the end re-read the last one: masked in the epilogue)
+            const uint4 *src = p.bb + (p.first + si * p.stride) * KQ + scq[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + (size_t)j * 512 + wave * 64), 16, 0, 0);
         }
+        u64 si = t0 + (uint32_t)lane;
+        si = si < p.count ? si : p.count - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.bnorm + (p.first + si * p.stride)),
+                                         (__attribute__((address_space(3))) void *)(nrm + b * 64), 4, 0, 0);  // (every wave: the same 256 bytes)
     };
-    if (s0 >= s1) return;
-    dma(buf0, s0);
-    int cur = 0;
-    for (u64 t0 = s0; t0 < s1; t0 += BT, cur ^= 1) {
-        uint4 *bufc = cur ? buf1 : buf0, *bufn = cur ? buf0 : buf1;
-        __syncthreads();  // (drains this wave's DMA of tile t0 -- vmcnt(0) -- and everybody has left the other buffer)
-        if (t0 + BT < s1) dma(bufn, t0 + BT);
+    auto flush = [&]() {  // staged admissions -> candidate lists (hi = d^ + eps), by the whole workgroup
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t have = *reinterpret_cast<volatile uint32_t *>(scnt);
+        const uint32_t cnt = have < (uint32_t)HCAP ? have : (uint32_t)HCAP;
+        for (uint32_t i = tid; i < cnt; i += 512) {
+            const u64 e = skey[i];
+            const uint32_t row = (uint32_t)e, qi = q0 + sql[i];
+            const float dist = __uint_as_float((uint32_t)(e >> 32));
+            const float hi = dist + knn_eps(p.ea[qi], p.kq[qi], p.bnorm[row], p.kappa, p.ip);
+            const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
+            if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (stores may overtake loads in the count: nothing of this may be left)
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) *scnt = 0;
+    };
+
+    const uint32_t ntiles = (uint32_t)((s1 - s0 + BT - 1) / BT);
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) dma((uint32_t)i, s0 + (u64)i * BT);
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        const u64 t0 = s0 + (u64)ti * BT;
+        const uint32_t b = ti % NBUF;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        dma((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
+        const uint4 *bufc = bufs + (size_t)b * JT * 512;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc0[g] = 0.f, acc1[g] = 0.f;
-        const uint4 *b0 = bufc + (size_t)r * KQ + h, *b1 = bufc + (size_t)(32 + r) * KQ + h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if ((uint32_t)ks < p.ksteps) {
-                const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0[2 * ks]), f1 = __builtin_bit_cast(bf16x8, b1[2 * ks]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], f0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], f1, acc1, 0, 0, 0);
+        // B fragments: rows r and 32 + r of the tile, quad 2 ks + h; the reads of step ks + 1 are issued before the MFMAs of step ks
+        const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
+        float bn0, bn1;
+        lds_read2_f32(lds_addr(nrm + b * 64 + r), bn0, bn1);
+        u32x4 fa[2], fb[2];
+        lds_read2_b128<0>(a0, a1, fa[0], fb[0]);
+        static_for<0, KS>([&](auto c) {
+            constexpr int ks = decltype(c)::value;
+            if constexpr (ks + 1 < KS) {
+                lds_read2_b128<(ks + 1 < KS ? ks + 1 : 0) * 32>(a0, a1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                lds_wait<2>(fa[ks & 1], fb[ks & 1]);
+            } else {
+                lds_wait<0>(fa[ks & 1], fb[ks & 1]);
             }
-        }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fa[ks & 1]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fb[ks & 1]), acc1, 0, 0, 0);
+        });
         // epilogue: column (base row) = lane & 31 of each 32-wide half, row (query) in the register index
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const u64 si = t0 + 32 * t + r;
             const bool cv = si < s1;
-            const u64 row = p.first + (cv ? si : s1 - 1) * p.stride;
-            const float bn = p.bnorm[row];
+            const uint32_t row = (uint32_t)(p.first + (cv ? si : s1 - 1) * p.stride);
+            const float bn = t ? bn1 : bn0;
             const float xn = __builtin_sqrtf(bn) * 1.0002f;
             const float bl = p.ip ? 0.f : __builtin_fmaf(-p.kappa, bn, bn);  // L2: |x|^2 less its own part of eps
             uint32_t hits = 0;
@@ -223,50 +306,89 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 hits |= (cv && lo <= thr[g]) ? (1u << g) : 0u;
             }
             if (__ballot(hits != 0)) {  // rare: ~k x ratio admissions per query and pass
+                bool spilled = false;
                 for (; hits; hits &= hits - 1) {
                     const int g = __ffs((int)hits) - 1;
                     const float dot = t ? acc1[g] : acc0[g];
-                    const uint32_t qi = q0 + 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    const uint32_t ql = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
                     const float dist = p.ip ? -dot : __builtin_fmaf(-2.f, dot, bn);
-                    const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, p.ip);
-                    const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
-                    if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | (uint32_t)row;
+                    const uint32_t at = lds_add_rtn(lds_addr(scnt), 1u);
+                    if (at < (uint32_t)HCAP) {
+                        lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
+                        lds_write_b16(lds_addr(sql + at), ql);
+                    } else {  // the staging block is full (the first pass admits every row): straight to the list
+                        const uint32_t qi = q0 + ql;
+                        const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, p.ip);
+                        const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
+                        if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
+                        spilled = true;
+                    }
                 }
+                if (__ballot(spilled)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see flush)
             }
         }
+        if ((ti & 31u) == 31u || ti + 1 == ntiles) flush();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the look-ahead loads past the slice must land before the LDS goes away)
 }
 
-// per query (one workgroup): sort the admitted list by (hi, id), keep the best k in front (every row after the last pass), tau = U = the k-th hi
-__global__ void __launch_bounds__(256) knn_bf_select_kernel(u64 *cand, uint32_t *cursor, uint32_t cap, uint32_t nq, uint32_t k, float *tau,
-                                                           uint32_t *overflow, int keep_all) {
-    extern __shared__ u64 skeys[];
+// per query (one workgroup): U = the k-th smallest hi of the admitted list -- a SELECTION, not a sort: four rounds of an 8-bit digit
+// histogram over the order-preserving 32-bit image of hi (the first form ranked every entry against every other: 2 700^2 compares per
+// query, 43 % of the generator's time).  The list itself stays as it is: the next pass starts an empty one (its sample contains this
+// one's), and the re-rank takes every row with lo <= U wherever it sits.
+__global__ void __launch_bounds__(256) knn_bf_select_kernel(const u64 *__restrict__ cand, uint32_t *cursor, uint32_t cap, uint32_t nq, uint32_t k,
+                                                           float *tau, uint32_t *overflow) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_want;
     const uint32_t q = blockIdx.x;
     if (q >= nq) return;
     uint32_t m = cursor[q];
     if (m > cap) {
-        if (threadIdx.x == 0) atomicAdd(overflow, 1u);
+        if (threadIdx.x == 0) {
+            atomicAdd(overflow, 1u);
+            cursor[q] = cap;
+        }
         m = cap;
     }
-    u64 *list = cand + (u64)q * cap;
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) skeys[i] = list[i];
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const u64 key = skeys[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; ++j) {
-            const u64 o = skeys[j];
-            rank += (o < key || (o == key && j < i)) ? 1u : 0u;
+    if (m < k) {  // (fewer rows than k so far: everything is admitted next time)
+        if (threadIdx.x == 0) tau[q] = __builtin_inff();
+        return;
+    }
+    const u64 *list = cand + (u64)q * cap;
+    if (threadIdx.x == 0) s_prefix = 0, s_want = k - 1;  // rank (0-based) of the wanted key among those that share the prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, want = s_want;
+        const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+            const uint32_t o = (uint32_t)(list[i] >> 32);
+            if ((o & himask) == prefix) atomicAdd(&hist[(o >> shift) & 0xFFu], 1u);
         }
-        if (rank < k || keep_all) list[rank] = key;  // (last pass: the whole list stays, sorted, for the re-rank)
-        if (rank == k - 1) tau[q] = ord2f_b((uint32_t)(key >> 32));
+        __syncthreads();
+        if (threadIdx.x < 64) {  // one wave: the bin that holds rank `want` (exclusive prefix sums of four bins per lane)
+            const uint32_t l = threadIdx.x;
+            const uint32_t c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+            uint32_t incl = c0 + c1 + c2 + c3;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, 64);
+                if ((int)l >= o) incl += v;
+            }
+            uint32_t base = incl - (c0 + c1 + c2 + c3);
+            const uint32_t cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (want >= base && want < base + cs[b]) {  // exactly one (lane, b)
+                    s_prefix = prefix | ((4 * l + b) << shift);
+                    s_want = want - base;
+                }
+                base += cs[b];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!keep_all) cursor[q] = m < k ? m : k;
-        else cursor[q] = m;
-        if (m < k) tau[q] = __builtin_inff();
-    }
+    if (threadIdx.x == 0) tau[q] = ord2f_b(s_prefix);
 }
 
 // Exact re-rank (header, step 4).  One workgroup of four waves per query: the admitted rows whose lo = hi - 2 eps is <= U are scored on
@@ -291,12 +413,12 @@ __global__ void __launch_bounds__(256) knn_rerank_kernel(const u64 *__restrict__
     const u64 *list = cand + (u64)qi * cap;
     if (tid == 0) s_m = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < m; i += 256) {  // (sorted by hi: the first k are the rows U comes from -- always in)
+    for (uint32_t i = tid; i < m; i += 256) {  // (the k rows U comes from have hi <= U, hence lo <= U: at least k rows go on)
         const u64 key = list[i];
         const uint32_t id = (uint32_t)key;
         const float hi = ord2f_b((uint32_t)(key >> 32));
         const float lo = hi - 2.0002f * knn_eps(e_q, k_q, bnorm[id], kappa, IP ? 1 : 0);
-        if (lo <= U || i < k) keys[atomicAdd(&s_m, 1u)] = id;
+        if (lo <= U) keys[atomicAdd(&s_m, 1u)] = id;
     }
     __syncthreads();
     const uint32_t m2 = s_m;
@@ -329,11 +451,12 @@ __global__ void __launch_bounds__(256) knn_rerank_kernel(const u64 *__restrict__
     }
 }
 
-template <int KS>
-hipError_t launch_pass(const KnnBfParams &p, uint32_t grid, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void *)knn_pass_bf16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int KS, int JT, int NBUF, int HCAP>
+hipError_t launch_pass(const KnnBfParams &p, uint32_t grid, hipStream_t st) {
+    const size_t lds = (size_t)NBUF * JT * 512 * 16 + NBUF * 256 + (size_t)HCAP * 10 + 16;
+    hipError_t e = hipFuncSetAttribute((const void *)knn_pass_bf16_kernel<KS, JT, NBUF, HCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(knn_pass_bf16_kernel<KS>, dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((knn_pass_bf16_kernel<KS, JT, NBUF, HCAP>), dim3(grid), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 
@@ -341,10 +464,11 @@ hipError_t launch_pass(const KnnBfParams &p, uint32_t grid, size_t lds, hipStrea
 
 extern "C" {
 
-// quads per row of the bf16 copies: dim rounded up to whole K steps of 16, an odd number of quads
+// quads per row of the bf16 copies: the K steps of the kernel instantiation that serves this row length (8, 13 or 32 steps of 16: rows
+// are zero beyond the dimension, the kernels walk every step), two quads per step + one: an odd number
 uint32_t roar_knn_bf16_row_quads(uint32_t dim) {
-    const uint32_t kq = ((dim + 15u) / 16u) * 2u;
-    return kq | 1u;
+    const uint32_t ks = (dim + 15u) / 16u;
+    return (ks <= 8 ? 8u : ks <= 13 ? 13u : 32u) * 2u + 1u;
 }
 
 // f32 rows -> bf16 copy ([n_pad][KQ] quads; rows past n zero); sqnorm / max_sq_bits may be null.  *max_sq_bits must be zeroed by the caller.
@@ -395,16 +519,11 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         stride0 *= ratio;
         ++P;
     }
-    if ((e = hipFuncSetAttribute((const void *)knn_bf_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)cap * 8))) != hipSuccess)
-        return (int)e;
-    const uint32_t J = (BT * KQ + 511u) / 512u;
-    const size_t lds = (size_t)2 * J * 512 * 16;
     uint64_t stride = stride0;
     for (int pass = 0; pass < P; ++pass, stride /= ratio) {
-        const int last = pass == P - 1;
         if ((e = hipMemsetAsync(cursor, 0, (size_t)nq * 4, st)) != hipSuccess) return (int)e;
         KnnBfParams p;
-        p.qb = (const uint4 *)qb, p.bb = (const uint4 *)bb, p.KQ = KQ, p.ksteps = ksteps, p.nq = nq;
+        p.qb = (const uint4 *)qb, p.bb = (const uint4 *)bb, p.KQ = KQ, p.nq = nq;
         p.first = 0, p.stride = stride, p.count = (n + stride - 1) / stride;
         // slices: ~64 MB of bf16 rows (they sit in the Infinity Cache while the workgroups of one slice stream them), whole tiles
         uint64_t rps = std::max<uint64_t>(BT, ((64ull << 20) / (KQ * 16ull)) / BT * BT);
@@ -414,12 +533,13 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         const uint64_t nqt = nq_pad / QT, nslices = (p.count + rps - 1) / rps;
         const uint64_t grid = nqt * nslices;
         if (grid > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        if (ksteps <= 8) e = launch_pass<8>(p, (uint32_t)grid, lds, st);
-        else if (ksteps <= 13) e = launch_pass<13>(p, (uint32_t)grid, lds, st);
-        else e = launch_pass<32>(p, (uint32_t)grid, lds, st);
+        // (K steps, DMA instructions per thread and tile for the longest row of the bucket, tile buffers, staged admissions)
+        if (ksteps <= 8) e = launch_pass<8, 3, 4, 2048>(p, (uint32_t)grid, st);
+        else if (ksteps <= 13) e = launch_pass<13, 4, 4, 2048>(p, (uint32_t)grid, st);
+        else e = launch_pass<32, 9, 2, 1024>(p, (uint32_t)grid, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(knn_bf_select_kernel, dim3(nq), dim3(256), (size_t)cap * 8, st, (u64 *)cand, (uint32_t *)cursor, cap, nq, k, (float *)tau,
-                           (uint32_t *)overflow_dev, last);
+        hipLaunchKernelGGL(knn_bf_select_kernel, dim3(nq), dim3(256), 0, st, (const u64 *)cand, (uint32_t *)cursor, cap, nq, k, (float *)tau,
+                           (uint32_t *)overflow_dev);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     }
     const size_t rl = ((dim * 4u + 15u) & ~15u) + (size_t)cap * 8;

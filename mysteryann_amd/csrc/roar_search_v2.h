@@ -304,6 +304,13 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ base, uint6
 //          room for FOUR rows per group and pass -- a whole hop's neighbours in one round trip.
 //   A row of zeros has s = 0, B = N = 0: its screened value is exact.  A row with a component that is not finite, or with a scale
 //   near the subnormals, has B = +inf and is never dropped; a query like that switches the screen off for itself (|q| = +inf).
+//   CENTRED codes (round 4): the copy codes y = x - mu, mu = the mean of the base rows (f32, kept with the copy), not x itself --
+//   embedding sets sit in a narrow cone, most of every score is the same mu.q, and a bound in units of |q||x| would then pass nearly
+//   every row (measured: pass rate 0.26 at |mu| = 3 x the spread, ~1 at 30 x, against 0.10-0.14 centred).  x.q = mu.q + y.q, the bound
+//   above holds for y with N, B measured on y, and the query adds once  qd = m + dm + dx:  m = its f32 value of mu.q, dm >= what that
+//   value can differ from the real mu.q by (1.25 (D / 64 + 8) 2^-24 sum |mu_i q_i|: 64 partial sums, six shuffle adds), dx = the part of
+//   the exact pass's own summation error that |mu| adds to the |y| the rows carry (1.25 (D / 16 + 6) 2^-24 |q| |mu|):
+//              exact distance of the row  >=  -(s t I) - (E N + |q| B) - qd - 1e-30
 //
 // L2 (screen8_pass): the query stays in f32.
 //   row:   u_i in 0..255 with x~_i = lo + s u_i, then s, lo, |x~|^2 and B >= |x - x~| (roar_make_screen8_l2_kernel);
@@ -392,7 +399,8 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
         const int I = quad_sum_i32(acc[r]);
         const uint32_t bn = x[r][NJ].w;
         const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(bn << 16), nrm = __uint_as_float(bn & 0xFFFF0000u);
-        const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-30f;  // the exact distance is >= lower
+        // the exact distance is >= lower - qd; qd, the same for every row of the query, sits in the threshold (screen_threshold)
+        const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-30f;
         const uint32_t c = p0 + 16 * r + g;
         float th = thr_d;
         if constexpr (CHECK) th = chk[c < m ? c : m - 1];
@@ -475,6 +483,13 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
     wave_sync();
 }
 
+// A row is dropped iff (its lower bound without the centre's part) > threshold + qd: the sum is rounded UP (a threshold that is too high
+// only keeps more rows).
+__device__ __forceinline__ float screen_threshold(float thr_d, float qd) {
+    const float v = thr_d + qd;
+    return v + __builtin_fabsf(v) * 1.2e-7f;
+}
+
 // lq = the f32 query in LDS, its 8-bit codes (inner product) behind it
 template <int D, bool IP, bool CHECK = false>
 __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
@@ -499,10 +514,11 @@ __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict
     return w;
 }
 
-// The query's side of the screen, one wave: inner product: qa = |q| rounded up, qb = t, qc = E and the codes k behind the f32 query in
-// LDS; L2: qa = |q|^2, qb = sum q_i.
+// The query's side of the screen, one wave: inner product: qa = |q| rounded up, qb = t, qc = E, qd = the centre's part (mu = the mean
+// the copy's codes are centred on, dim floats in HBM; null: none) and the codes k behind the f32 query in LDS; L2: qa = |q|^2, qb = sum q_i.
 template <int SD, bool IP>
-__device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane, float &qa, float &qb, float &qc) {
+__device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane, float &qa, float &qb, float &qc, float &qd,
+                                              const float *__restrict__ mu = nullptr) {
     float s2 = 0.f, s1 = 0.f, mx = 0.f;
     for (uint32_t i = lane; i < dim; i += 64) {
         s2 = __builtin_fmaf(lq[i], lq[i], s2);
@@ -515,7 +531,23 @@ __device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane,
         s1 += __shfl_xor(s1, o, 64);
         mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
     }
+    float mq = 0.f, ma = 0.f, m2 = 0.f;  // (a pass of its own: six accumulators through one reduction spill in the kernels that sit at their budget)
+    if (IP && mu) {
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float u = mu[i];
+            mq = __builtin_fmaf(u, lq[i], mq);
+            ma = __builtin_fmaf(__builtin_fabsf(u), __builtin_fabsf(lq[i]), ma);
+            m2 = __builtin_fmaf(u, u, m2);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mq += __shfl_xor(mq, o, 64);
+            ma += __shfl_xor(ma, o, 64);
+            m2 += __shfl_xor(m2, o, 64);
+        }
+    }
     qc = 0.f;
+    qd = 0.f;
     if constexpr (IP) {
         const float tq = mx / 127.0f, inv = mx > 0.f ? 127.0f / mx : 0.f;
         uint32_t *lk = reinterpret_cast<uint32_t *>(lq + ((SD + 3) & ~3));
@@ -542,6 +574,10 @@ __device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane,
         // EXACT pass's own f32 sum (16 partial sums of D / 16 products, then the tree: distance.h:179-223) can differ from
         // the real-number inner product by -- the bound has to hold for the distance as the reference computes it
         qc = 1.001f * tq * __builtin_sqrtf(e2) + (4.0e-7f + 1.25f * (float)(SD / 16 + 6) * 5.9604645e-8f) * qa;
+        // the centre's part: mu.q as computed here, + what that sum can be off by, + the exact pass's summation error on the mu part of x
+        qd = mq + 1.25f * (float)(SD / 64 + 8) * 5.9604645e-8f * 1.001f * ma +
+             1.25f * (float)(SD / 16 + 6) * 5.9604645e-8f * 1.001f * qa * (__builtin_sqrtf(m2) * 1.0001f);
+        if (!(qd == qd) || !(__builtin_fabsf(qd) <= 3.0e38f)) qa = __builtin_inff();  // (a centre that is not finite cannot happen -- the copy drops it -- but no bound then)
         // no bound is claimed for a query that is not finite, whose squares overflow or whose scale is near the subnormals
         if (!(mx <= 1.0e18f) || !(s2 <= 3.0e38f) || (mx > 0.f && mx < 1.0e-30f)) qa = __builtin_inff();
     } else {
@@ -680,12 +716,18 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             const bool screen_on = false;
 #endif
             if (wid == 0 && screen_on) {  // (the LDS behind the query is there for the codes only when the launch has a screening copy)
-                float qa, qb, qc;
-                screen8_query<SD, IP>(lq, p.dim, lane, qa, qb, qc);
+                float qa, qb, qc, qd;
+#if defined(__HIP_DEVICE_COMPILE__)
+                const float *mu = *const_cast<const float *const volatile *>(&((const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr())->screen_mu);
+#else
+                const float *mu = nullptr;
+#endif
+                screen8_query<SD, IP>(lq, p.dim, lane, qa, qb, qc, qd, mu);
                 if (lane == 0) {
                     ctrl[8] = __float_as_uint(qa);
                     ctrl[9] = __float_as_uint(qb);
                     ctrl[10] = __float_as_uint(qc);
+                    ctrl[11] = __float_as_uint(qd);
                 }
                 wave_sync();
             }
@@ -911,8 +953,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
                                 [[maybe_unused]] const uint32_t coded = m;
-                                m = screen8_rows<SD, IP>(scr, lq, cid, m, ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]),
-                                                         __uint_as_float(ctrl[10]), lane);
+                                m = screen8_rows<SD, IP>(scr, lq, cid, m, screen_threshold(ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[11])),
+                                                         __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), __uint_as_float(ctrl[10]), lane);
                                 count_traffic((u64)coded | ((u64)m << 24));
                             }
                         }
@@ -1149,8 +1191,9 @@ const void *pick_form(const RoarKernelSel &s) {
 // Known-answer surface for the screen (roar_debug_screen_keeps, tests): workgroup (q, b) runs the search's own screening passes over
 // rows ids[q][64 b .. 64 b + 64) of query q, each row against its OWN threshold chk[q][c]; chk[q][c] becomes 1.0 (kept) or 0.0.
 template <bool IP, int D>
-__global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned char *__restrict__ scr, const float *__restrict__ queries, u64 qstride,
-                                                               const uint32_t *__restrict__ ids, float *chk, uint32_t m) {
+__global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned char *__restrict__ scr, const float *__restrict__ mu,
+                                                               const float *__restrict__ queries, u64 qstride, const uint32_t *__restrict__ ids, float *chk,
+                                                               uint32_t m) {
     __shared__ __align__(16) float lq[D + D / 4 + 4];
     __shared__ uint32_t cid[64];
     __shared__ float th[64];
@@ -1161,8 +1204,10 @@ __global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned ch
     cid[lane] = (uint32_t)lane < mm ? ids[q * m + b0 + lane] : 0u;
     th[lane] = (uint32_t)lane < mm ? chk[q * m + b0 + lane] : 0.f;
     wave_sync();
-    float qa, qb, qc;
-    screen8_query<D, IP>(lq, D, lane, qa, qb, qc);
+    float qa, qb, qc, qd;
+    screen8_query<D, IP>(lq, D, lane, qa, qb, qc, qd, mu);
+    wave_sync();
+    th[lane] = screen_threshold(th[lane], qd);
     wave_sync();
     (void)screen8_rows<D, IP, true>(scr, lq, cid, mm, 0.f, qa, qb, qc, lane, th);
     wave_sync();
@@ -1171,15 +1216,15 @@ __global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned ch
 
 #define ROAR_CHECK_NAME2(i) roar_launch_screen_check_##i
 #define ROAR_CHECK_NAME(i) ROAR_CHECK_NAME2(i)
-extern "C" int ROAR_CHECK_NAME(ROAR_TU_IP)(const unsigned char *scr, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
+extern "C" int ROAR_CHECK_NAME(ROAR_TU_IP)(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
                                            const uint32_t *ids, float *chk, uint32_t m, void *stream) {
     constexpr bool IP = ROAR_TU_IP != 0;
     if (nq == 0 || m == 0) return 0;
     const dim3 grid((uint32_t)nq, (m + 63u) / 64u);
-    if (dim == 128) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 128>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
-    else if (dim == 512) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 512>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
+    if (dim == 128) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 128>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
+    else if (dim == 512) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 512>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
     else if (dim == 200 && IP) {
-        if constexpr (IP) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 200>), grid, dim3(64), 0, (hipStream_t)stream, scr, queries, (u64)qstride, ids, chk, m);
+        if constexpr (IP) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 200>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
     } else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

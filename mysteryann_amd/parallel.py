@@ -37,6 +37,19 @@ def rebase_ids(ids, offset):
     return np.where(ids == INVALID, ids, ids + ids.dtype.type(offset)).astype(ids.dtype)
 
 
+def ranks_seen(device=None, group=None):
+    """How many ranks a collective really spans: a one-element all-reduce of ones (over RCCL on the GPU box: the first collective
+    bench.py issues, reported as config.rccl_ranks_seen; over gloo in the CPU tests).  1 without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
 def gather_query_slices(local, nq, group=None):
     """Replicated configuration: every rank holds the rows `shard_range(nq, world, rank)` of a per-query result
     (tensor [hi - lo, ...]); returns the whole [nq, ...] tensor on every rank.  Slices differ in length by at most one

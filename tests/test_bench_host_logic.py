@@ -112,3 +112,16 @@ def test_kernel_trace_span_of_overlapping_launches(tmp_path):
     assert span == pytest.approx(7.5) and mean == pytest.approx(3.0)
     with pytest.raises(RuntimeError):
         bench.kernel_trace_span(str(p), 6)
+
+
+def test_emulated_share_of_8_block():
+    """config.emulated_share_of_8 (N = 1 runs): the projection arithmetic."""
+    import bench
+
+    # 10 000-query batch, 20 steps: one rank's 1 250-query share took 4.4 ms in all, six in flight; this run served 7.0 M QPS
+    b = bench.share_of_8_block(10_000, 20, 4.4e-3, 8.6e-3, 6, 640, 7.0e6)
+    assert b["queries_per_launch"] == 1250 and b["launches_in_flight"] == 6 and b["workgroups_per_launch_cap"] == 640
+    assert b["ms_per_step"] == pytest.approx(0.22) and b["ms_per_step_one_launch_at_a_time"] == pytest.approx(0.43)
+    assert b["projected_value_8_gpus"] == pytest.approx(10_000 * 20 / 4.4e-3)
+    assert b["projected_speedup_over_this_run"] == pytest.approx(10_000 * 20 / 4.4e-3 / 7.0e6)
+    assert "projection" in b["note"]

@@ -669,10 +669,11 @@ def test_exact_knn_generator_matches_brute_force(metric, d, k, knn_mode, built_l
     rng = np.random.default_rng(d + k)
     base = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal((nq, d)).astype(np.float32)
-    if knn_mode == 0:  # what a bound in units of |q| max|x| has to survive: a few rows 30 x longer than the others, a zero row, a zero query
+    if knn_mode == 0:  # what the bound has to survive: a few rows 30 x longer than the others (it is per row), a zero row, a zero query
         base[:5] *= 30.0
         base[7] = 0.0
-        q[3] = 0.0
+        if metric == 0:  # (inner product: every row ties at 0 for a zero query -- no top k to find, the lists overflow in either form)
+            q[3] = 0.0
     idx = mi.IndexBipartite(d, n, metric, None)
     idx.SetBaseData(base)
     idx.set_option("knn_mode", knn_mode)
@@ -694,7 +695,10 @@ def test_exact_knn_generator_matches_brute_force(metric, d, k, knn_mode, built_l
     want = order[:, :k]
     scale = np.abs(np.take_along_axis(full, want, 1)).max(axis=1)
     gap = np.take_along_axis(full, order[:, k:k + 1], 1)[:, 0] - np.take_along_axis(full, order[:, k - 1:k], 1)[:, 0]
-    clear = gap > 1e-5 * scale  # queries whose top-k set is unambiguous in f32
+    # queries whose top-k set is unambiguous in f32 (rounding of a distance scales with |q||x| of the rows AROUND the k-th: the few
+    # long rows of the bf16 case sit at the top of an inner-product list and would otherwise set the yardstick for everybody)
+    kth = np.abs(np.take_along_axis(full, order[:, k - 1:k], 1)[:, 0]) + (q64 ** 2).sum(1) ** 0.5 * np.median((b64 ** 2).sum(1) ** 0.5)
+    clear = gap > 1e-5 * np.minimum(scale, kth)
     assert clear.mean() > 0.9
     got_sets = np.sort(ids[clear], axis=1)
     assert np.array_equal(got_sets, np.sort(want[clear], axis=1))
@@ -822,13 +826,59 @@ def test_launch_plan_calibration_is_cached_per_band_and_follows_the_options(buil
     idx.close()
 
 
+def test_auto_plan_on_a_graph_nobody_tuned_for(built_lib):
+    """A random digraph of average degree 64 over 96-d rows (no compile-time row length, no screening kernel; nothing like the
+    two graphs rounds 1-3 tuned their plan table on): the calibrated AUTO plan must be within 5 % of the best explicit setting of
+    visited form x table size, at a short and at a long pool; results equal the oracle's."""
+    import torch
+
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 200_000, 96, 6144
+    base, q, off, nbrs = _random_case(n, d, nq, 0, seed=64, maxdeg=128)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(17, off, nbrs)
+    idx.set_option("hub_mode", 1)
+    qd = torch_pad(q, idx.info("dim_padded"))
+
+    def best_ms(L, reps=4):
+        best = 1e9
+        for _ in range(reps):
+            out = idx.SearchRoarGraphBatchDevice(qd, K, L)
+            torch.cuda.synchronize()
+            best = min(best, idx.info("last_kernel_ns") / 1e6)
+        return best, out
+
+    for L in (60, 700):
+        times = {}
+        idx.set_option("calibrate", 0)
+        for mode, ve in ((3, 2048), (3, 4096), (3, 8192), (3, 16384), (0, 0)):
+            idx.set_option("visited_mode", mode)
+            idx.set_option("vis_entries", ve)
+            times[(mode, ve)], _ = best_ms(L)
+        idx.set_option("visited_mode", 2)
+        idx.set_option("vis_entries", 0)
+        idx.set_option("calibrate", 1)
+        t_auto, out = best_ms(L)
+        assert idx.info("last_plan_calibrated") == 1
+        assert t_auto <= 1.05 * min(times.values()) + 0.01, (L, times, t_auto, idx.info("last_visited_mode"), idx.info("last_vis_entries"))
+        o = oracle.search_batch(base, off, nbrs, 17, q[:256], K, L, 0, threads=8)
+        for key in ("ids", "dists", "hops"):
+            assert np.array_equal(out[key][:256].cpu().numpy().view(o[key].dtype), o[key]), (L, key)
+    idx.close()
+
+
 def test_auto_screen_decision_follows_the_measured_times(built_lib):
-    """The screen's bound is in units of |q||x|: on a set whose rows share a large common component (a narrow cone: here 30 x the
-    isotropic part) every score of a hop lies within the bound's slack of the reject threshold, the screen passes (nearly) every
-    row on to the exact pass -- a second dependent round trip for nothing; on the plain isotropic set (offset 0: scores spread
-    over many slacks) it still drops most rows.  AUTO does not guess from the dimension any more: it times both on the caller's
-    own queries and takes the faster one -- checked here against the test's own timing of the two forced settings.  Results
-    equal the oracle's in every setting."""
+    """Where the 8-bit screen pays is a property of the data -- how many of a hop's neighbours its bound can drop:
+      * isotropic rows (t2i-hard, offset 0): scores spread over many slacks of the bound, most rows are dropped;
+      * a narrow cone (every row = a common component 30 x the isotropic part + that part): a bound in units of |q||x| would pass
+        nearly every row -- the codes are centred on the mean of the rows (round 4), and the pass rate is that of the isotropic part;
+      * tight clusters (64 centres, rows within 0.2 % of their centre): a node's neighbours are its cluster, their scores differ by
+        less than the bound's slack, the screen passes everything on -- a second dependent round trip for nothing.
+    AUTO does not guess from the row length any more: it times both forms on the caller's own queries and takes the faster one --
+    checked here against this test's own timing of the two forced settings.  Results equal the oracle's in every setting."""
     import torch
 
     import oracle
@@ -836,9 +886,23 @@ def test_auto_screen_decision_follows_the_measured_times(built_lib):
     from mysteryann_amd import synth
 
     n, nq, d, L = 400_000, 8192, 200, 50
+
+    def clustered(seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        centres = torch.randn((64, d), generator=g, device="cuda") * 0.08
+
+        def draw(m, spread):
+            c = centres[torch.randint(0, 64, (m,), generator=g, device="cuda")]
+            return (c + spread * 0.08 * torch.randn((m, d), generator=g, device="cuda")).contiguous()
+
+        return draw(n, 0.002), draw(nq, 0.02), draw(40_000, 0.02)
+
     rates = {}
-    for offset in (30.0, 0.0):
-        base, q, learn = synth.t2i_hard_torch(n, nq, d, seed=11, n_learn=40_000, offset=offset)
+    for name in ("isotropic", "narrow cone", "tight clusters"):
+        if name == "tight clusters":
+            base, q, learn = clustered(13)
+        else:
+            base, q, learn = synth.t2i_hard_torch(n, nq, d, seed=11, n_learn=40_000, offset=30.0 if name == "narrow cone" else 0.0)
         idx = mi.IndexBipartite(d, n, mi.INNER_PRODUCT, None)
         idx.SetBaseData(base)
         lists, _ = idx.ExactKnnDevice(learn, 100, want_dists=False)
@@ -854,7 +918,7 @@ def test_auto_screen_decision_follows_the_measured_times(built_lib):
         idx.SetTrafficCounters(None)
         t = blk.cpu().numpy().astype(np.int64).sum(axis=0)
         cm = int(forced["cmps"].cpu().numpy().astype(np.int64).sum())
-        rates[offset] = (t[1] - nq - (cm - t[0])) / max(t[0], 1)  # rows the screen let through / rows it scored
+        rates[name] = (t[1] - nq - (cm - t[0])) / max(t[0], 1)  # rows the screen let through / rows it scored
 
         def best_ms(reps=5):
             best = 1e9
@@ -874,14 +938,14 @@ def test_auto_screen_decision_follows_the_measured_times(built_lib):
         t_auto, auto = best_ms()
         assert idx.info("last_plan_calibrated") == 1
         picked = 2 if idx.info("last_screen") else 1
-        assert t_auto <= 1.06 * min(times.values()) + 0.01, (offset, times, t_auto)
-        assert times[picked] <= 1.06 * min(times.values()) + 0.01, (offset, times, picked)
+        assert t_auto <= 1.06 * min(times.values()) + 0.01, (name, times, t_auto)
+        assert times[picked] <= 1.06 * min(times.values()) + 0.01, (name, times, picked)
         o = oracle.search_batch(base.cpu().numpy(), off, nbrs, ep, q[:512].cpu().numpy(), K, L, 1, threads=8)
         for key in ("ids", "dists", "hops"):
-            assert np.array_equal(auto[key][:512].cpu().numpy().view(o[key].dtype), o[key]), (offset, key)
-            assert np.array_equal(forced[key][:512].cpu().numpy().view(o[key].dtype), o[key]), (offset, key)
+            assert np.array_equal(auto[key][:512].cpu().numpy().view(o[key].dtype), o[key]), (name, key)
+            assert np.array_equal(forced[key][:512].cpu().numpy().view(o[key].dtype), o[key]), (name, key)
         idx.close()
-    assert rates[30.0] > 0.9 and rates[0.0] < rates[30.0], rates
+    assert rates["isotropic"] < 0.3 and rates["narrow cone"] < 0.3 and rates["tight clusters"] > 0.9, rates
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
@@ -924,7 +988,8 @@ def test_latency_kernel_four_waves_per_query(mode, golden_dir, built_lib):
     assert idx.info("last_waves_per_query") == 4  # at most one query per CU on a dense graph: the four-wave form
     idx.set_option("screen", 0)
     idx.SearchRoarGraphBatch(q, K, 50)
-    assert idx.info("last_waves_per_query") == 1  # (with the 8-bit screen few rows are left to score: one wave)
+    # (with the 8-bit screen few rows are left to score: one wave; AUTO takes the screen or not by what it measured)
+    assert idx.info("last_waves_per_query") == (1 if idx.info("last_screen") else 4)
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "lds"])
@@ -1405,12 +1470,20 @@ def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib)
             made.append(idx)
             idx.SetBaseData(base)
             idx.SetProjectionGraph(5, off, nbrs)
+            # (fixed plans: which kernel forms a calibration times depends on the clock, and the first launch of a form with more
+            # scratch makes the runtime grow its scratch arena -- device memory that stays, and looks like a leak to this test)
+            idx.set_option("calibrate", 0)
             for mode, hub, L in ((1, 1, 50), (0, 1, 50), (1, 2, 120), (3, 1, 300)):
                 idx.set_option("visited_mode", mode)
                 idx.set_option("hub_mode", hub)
                 idx.SearchRoarGraphBatch(q, K, L)
+            # one calibrated launch whose candidates are all the same kernel form (only the table size is open): scratch results
+            idx.set_option("calibrate", 1), idx.set_option("screen", 2), idx.set_option("hub_mode", 1)
+            idx.SearchRoarGraphBatch(q, K, 30)
             idx.Distances(q, ids)
             kid = np.zeros((nq, 5), np.uint32)
+            capi.check(lib.roar_exact_knn(idx._h, capi.f32p(q), nq, d, 5, capi.u32p(kid), None))
+            idx.set_option("knn_mode", 1)  # (both forms in every pass: the f32 form is also the fallback of the other)
             capi.check(lib.roar_exact_knn(idx._h, capi.f32p(q), nq, d, 5, capi.u32p(kid), None))
             rep = idx.Clone(0)
             made.append(rep)
@@ -1424,23 +1497,32 @@ def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib)
     free0 = torch.cuda.mem_get_info()[0]
     failures = absorbed = 0
     for nth in range(1, 400):
-        lib.roar_debug_fail_device_alloc_at(nth)
         left = 0
-        try:
-            scenario()
-            absorbed += 1  # e.g. no room for the spill lists: the launch runs the forgetful form instead
-        except mi.RoarError as e:
-            failures += 1
-            assert e.code == capi.ERR_DEVICE, (nth, e)
-        finally:
-            left = lib.roar_debug_fail_device_alloc_at(0)
-        torch.cuda.synchronize()
-        free = torch.cuda.mem_get_info()[0]
-        assert abs(free - free0) <= (4 << 20), (nth, free0 - free)
+        frees = []
+        for again in range(2):
+            # (twice with the same n: a failure path that leaks does so every time; what the runtime's allocator keeps for itself
+            # after a new ORDER of allocations -- the screening copy is made inside the first search when its allocation failed while
+            # the base rows were set -- it keeps once: 32 MiB chunks)
+            lib.roar_debug_fail_device_alloc_at(nth)
+            try:
+                scenario()
+                absorbed += 1 - again  # e.g. no room for the spill lists: the launch runs the forgetful form instead
+            except mi.RoarError as e:
+                failures += 1 - again
+                assert e.code == capi.ERR_DEVICE, (nth, e)
+            finally:
+                left = lib.roar_debug_fail_device_alloc_at(0)
+            torch.cuda.synchronize()
+            frees.append(torch.cuda.mem_get_info()[0])
+        assert abs(frees[1] - frees[0]) <= (4 << 20), (nth, frees[0] - frees[1])
+        assert free0 - frees[1] <= (256 << 20), (nth, free0 - frees[1])
         if left > 0:  # the scenario made fewer than nth allocations: every one of them has been failed once
             absorbed -= 1
             break
-    assert failures >= 20 and absorbed <= 6, (failures, absorbed)  # the scenario makes a few dozen device allocations
+    # the scenario makes a few dozen device allocations; absorbed by a documented fallback: no room for the spill lists (forgetful
+    # form), for the 8-bit screening copy (every row scored on f32), for a calibration's scratch results (default plan), for the
+    # workspaces of the bf16-screened exact kNN (eleven blocks: the f32 form runs instead)
+    assert failures >= 20 and absorbed <= 30, (failures, absorbed)
     scenario()  # and the library still works
 
 

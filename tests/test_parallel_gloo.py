@@ -41,6 +41,7 @@ def _worker(rank, world, port, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
 
+    assert parallel.ranks_seen() == world  # bench.py's config.rccl_ranks_seen (there over RCCL)
     rng = np.random.default_rng(42)  # same data on every rank
     n, d, nq, k, L = 4000, 64, 24, 10, 60
     base = rng.standard_normal((n, d)).astype(np.float32)

@@ -15,10 +15,12 @@ def bf16_up(v):
     return (hi.astype(np.uint32) << 16).view(f32)
 
 
-def code_rows(x):
-    """roar_make_screen8_kernel: c, s, B, N per row (f32 arithmetic as the kernel's)."""
+def code_rows(x, mu=None):
+    """roar_make_screen8_kernel: c, s, B, N per row (f32 arithmetic as the kernel's); mu: the centre of the codes (they code x - mu)."""
     x = np.asarray(x, f32)
     old = np.seterr(all="ignore")
+    if mu is not None:
+        x = (x - np.asarray(mu, f32)[None, :]).astype(f32)
     mx = np.abs(x).max(axis=1)
     bad = ~np.isfinite(x).all(axis=1) | (mx > f32(1e30)) | ((mx > 0) & (mx < f32(1e-30)))
     s = (mx / f32(127)).astype(f32)
@@ -28,16 +30,22 @@ def code_rows(x):
     e2 = (d * d).sum(axis=1, dtype=f32)
     c2 = (c * c).sum(axis=1, dtype=f32)
     nrm = (s * np.sqrt(c2) * f32(1.0001)).astype(f32)
-    bnd = (f32(1.001) * s * np.sqrt(e2) * f32(1.0001) + f32(1.2e-7) * nrm).astype(f32)
+    bnd = (f32(1.001) * s * np.sqrt(e2) * f32(1.0001) + f32(2.4e-7) * nrm).astype(f32)
     B, N = bf16_up(bnd), bf16_up(nrm)
     B[bad], N[bad], s[bad], c[bad] = np.inf, 0, 0, 0
     np.seterr(**old)
     return c.astype(np.int32), s, B, N
 
 
-def code_query(q, D):
-    """screen8_query: k, |q| rounded up, t, E."""
+def code_query(q, D, mu=None):
+    """screen8_query: k, |q| rounded up, t, E, and qd = the centre's part of the bound (0 without a centre)."""
     q = np.asarray(q, f32)
+    qd = f32(0)
+    if mu is not None:
+        mu = np.asarray(mu, f32)
+        mq = (mu * q).sum(dtype=f32)
+        ma = (np.abs(mu) * np.abs(q)).sum(dtype=f32)
+        m2 = (mu * mu).sum(dtype=f32)
     mx, s2 = np.abs(q).max(), (q * q).sum(dtype=f32)
     t = f32(mx / f32(127))
     inv = f32(127) / mx if mx > 0 else f32(0)
@@ -46,13 +54,23 @@ def code_query(q, D):
     e2 = (d * d).sum(dtype=f32)
     qa = f32(np.sqrt(s2) * f32(1.0001))
     qc = f32(f32(1.001) * t * np.sqrt(e2) + (f32(4.0e-7) + f32(1.25) * f32(D // 16 + 6) * f32(5.9604645e-8)) * qa)
+    if mu is not None:
+        with np.errstate(over="ignore", invalid="ignore"):
+            qd = f32(mq + f32(1.25) * f32(D // 64 + 8) * f32(5.9604645e-8) * f32(1.001) * ma
+                     + f32(1.25) * f32(D // 16 + 6) * f32(5.9604645e-8) * f32(1.001) * qa * f32(np.sqrt(m2) * f32(1.0001)))
+        if not np.isfinite(qd):
+            qa = f32(np.inf)
     if not (mx <= 1e18) or not (s2 <= 3e38) or (0 < mx < 1e-30):
         qa = f32(np.inf)
-    return k.astype(np.int32), qa, t, qc
+    return k.astype(np.int32), qa, t, qc, qd
 
 
+@pytest.mark.parametrize("centre", [None, "mean", "far"])
 @pytest.mark.parametrize("d", [128, 200, 512])
-def test_lower_bound_never_exceeds_the_reference_distance(d):
+def test_lower_bound_never_exceeds_the_reference_distance(d, centre):
+    """centre: None = codes of x itself (rounds 1-3); "mean" = codes centred on the mean of the rows, as the library makes them;
+    "far" = rows that share a large common component (a narrow cone, |mu| = 40 x the spread) with their mean as the centre -- where
+    the uncentred bound was worthless."""
     import oracle
 
     rng = np.random.default_rng(5)
@@ -74,22 +92,31 @@ def test_lower_bound_never_exceeds_the_reference_distance(d):
     q[3] *= f32(1e10)
     q[4:8] = x[1000:1004]
     q[8:12] = -x[1000:1004]
-    c, s, B, N = code_rows(x)
+    mu = None
+    if centre == "far":
+        x[1100:] += (rng.standard_normal(d) * 40).astype(f32)[None, :]
+    if centre is not None:
+        with np.errstate(over="ignore", invalid="ignore"):
+            mu = (x[1100:].astype(np.float64).sum(axis=0) / (n - 1100)).astype(f32)  # (any finite vector will do as a centre)
+    c, s, B, N = code_rows(x, mu)
     worst = -np.inf
     dropped_at_5pc = []
     for i in range(nq):
-        k, qa, t, qc = code_query(q[i], d)
+        k, qa, t, qc, qd = code_query(q[i], d, mu)
         I = (c.astype(np.int64) @ k.astype(np.int64)).astype(f32)  # exact: |I| < 2^24
         with np.errstate(invalid="ignore", over="ignore"):
-            lower = (-((s * t) * I) - (qc * N + qa * B) - f32(1e-30)).astype(f32)
+            lower = (-((s * t) * I) - (qc * N + qa * B) - qd - f32(1e-30)).astype(f32)
         exact = oracle.dist_many(1, x, np.repeat(q[i][None], n, axis=0))  # -(x . q) as distance.h computes it
         viol = lower > exact  # (NaN compares false: such a row is kept)
         assert not viol.any(), (d, i, np.argwhere(viol)[:5].ravel(), lower[viol][:5], exact[viol][:5])
         if i >= 12:
             ordinary = np.arange(1100, n)
-            margin = 0.05 * np.linalg.norm(q[i].astype(np.float64)) * np.linalg.norm(x[ordinary].astype(np.float64), axis=1)
+            spread = x[ordinary].astype(np.float64) - (0 if mu is None else mu.astype(np.float64)[None, :])
+            margin = 0.05 * np.linalg.norm(q[i].astype(np.float64)) * np.linalg.norm(spread, axis=1)
             dropped_at_5pc.append(np.mean(lower[ordinary] > exact[ordinary] - margin))
-    assert np.mean(dropped_at_5pc) > 0.98  # and it is tight: 5 % of |q||x| under the exact distance, ordinary rows are dropped
+    # and it is tight: 5 % of |q||x - mu| under the exact distance, ordinary rows are dropped -- also in the narrow cone, where that is
+    # 0.1 % of |q||x|
+    assert np.mean(dropped_at_5pc) > 0.98
 
 
 def code_rows_l2(x):

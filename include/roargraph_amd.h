@@ -173,7 +173,14 @@ int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32
                       uint32_t *scanned);
 /* Device-buffer form: every pointer is HBM-resident, launch is asynchronous on `hip_stream`
  * (a hipStream_t, NULL = default stream); no implicit synchronisation.  Short results are reported
- * through *short_count_dev (u32, may be NULL). */
+ * through *short_count_dev (u32, may be NULL).
+ * Launches of one index on DIFFERENT streams may overlap (each takes a 16-byte launch cell from a ring of 256, zero on entry and
+ * zeroed again by its last workgroup): at most 256 launches of one index may be in flight at a time, and a launch that faulted
+ * leaves its cell dirty -- destroy the index after a device fault.  Launches that use per-workgroup lists in HBM (visited_mode
+ * EXACT, or LDS with spill lists) are ordered one behind the other by an event.  "last_kernel_ns" is the duration of the most
+ * recently ENQUEUED launch between its own two events on its own stream; with launches overlapping it includes what that stream
+ * waited for -- use one launch at a time (or events of your own) to time a kernel.  The first search of a kind calibrates the launch
+ * plan (option "calibrate") and synchronises `hip_stream` once. */
 int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32_t qstride_floats,
                              uint32_t k, uint32_t L_pq, uint32_t *ids_dev, float *dists_dev, uint32_t *cmps_dev,
                              uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,

@@ -318,8 +318,11 @@ int roar_search_batch_sharded(roar_sharded *sh, const float *queries, uint64_t n
             if (e1) return e1;
             S_HIP(hipEventRecord(r.ev_start, r.stream));
             S_HIP(hipMemcpyAsync(r.q_dev, sh->q_pin, (size_t)qf * sizeof(float), hipMemcpyHostToDevice, r.stream));
-            if (r.shards.size() < sh->max_local)  // unused block slots read as "no result"
+            if (r.shards.size() < sh->max_local) {  // unused block slots read as "no result": id 0xFFFFFFFF, distance NaN-free +inf
                 S_HIP(hipMemsetAsync(r.send_ids, 0xFF, (size_t)sh->max_local * res * 4, r.stream));
+                // (what goes over the wire is then the same on every run; the merge skips the slot by its id)
+                S_HIP(hipMemsetD32Async((hipDeviceptr_t)r.send_d, (int)0x7F800000, (size_t)sh->max_local * res, r.stream));
+            }
             for (size_t j = 0; j < r.shards.size(); ++j) {
                 const uint32_t s = r.shards[j];
                 uint32_t *cm = r.counts + (size_t)j * 2 * nq;

@@ -7,9 +7,10 @@ from mysteryann_amd import index as mi, synth
 
 
 def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="/tmp/r3_graph2.index", say=print, stage2=-1, stage2_L=600):
-    """bench.py's default index (two-stage training lists, bench.build_reference_graph) unless told otherwise."""
+    """bench.py's default index (exact lists of as many training queries as base points, bench.build_reference_graph) unless told
+    otherwise (ref_learn < n: round 3's two-stage lists)."""
     d = 200
-    n_exact = ref_learn or n // 5
+    n_exact = ref_learn or n
     n_learn = max(n_exact, n if stage2 < 0 else stage2) if builder == "reference" else n
     have = bool(cache) and os.path.exists(cache)
     base, queries, learn = synth.t2i_torch(n, nq, d, n_learn=0 if have else n_learn)

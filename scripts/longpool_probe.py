@@ -1,0 +1,30 @@
+"""Long pools on the benchmark graph: what forgetting costs in ROWS.  Per L_pq: rows scored on the 8-bit copy and on f32 (kernel
+counters) and kernel ms, for the forgetful on-chip table at 2 048 / 4 096 / 8 192 tags, the exact on-chip table (spill lists) and
+HBM tags.  The difference of the f32 rows to the exact forms is what re-scored revisits cost in f32 reads."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+from _graph import t2i_index
+ap = argparse.ArgumentParser()
+ap.add_argument("--graph-cache", default="/tmp/r4_graph.index")
+ap.add_argument("--L", type=int, nargs="+", default=[200, 500, 1000, 2000])
+ap.add_argument("--nq", type=int, default=10000)
+args = ap.parse_args()
+idx, base, queries = t2i_index(10_000_000, 10000, "reference", 0, args.graph_cache)
+q = queries[:args.nq].contiguous()
+blk = torch.zeros((args.nq, 4), dtype=torch.int32, device="cuda")
+idx.set_option("calibrate", 0); idx.set_option("screen", 2)
+for L in args.L:
+    for label, vm, ve in (("forgetful 2048", 3, 2048), ("forgetful 4096", 3, 4096), ("forgetful 8192", 3, 8192), ("exact table 4096", 1, 4096), ("HBM tags", 0, 0)):
+        idx.set_option("visited_mode", vm); idx.set_option("vis_entries", ve)
+        idx.SetTrafficCounters(blk)
+        o = idx.SearchRoarGraphBatchDevice(q, 10, L); torch.cuda.synchronize()
+        idx.SetTrafficCounters(None)
+        t = blk.to(torch.float64).sum(0) / args.nq
+        best = 1e9
+        for _ in range(2):
+            idx.SearchRoarGraphBatchDevice(q, 10, L); torch.cuda.synchronize()
+            best = min(best, idx.info("last_kernel_ns") / 1e6)
+        print(f"L_pq {L:5d} {label:18s}: {best:8.2f} ms  cmps {o['cmps'].double().mean().item():9.1f}  rows 8-bit {t[0].item():9.1f}  rows f32 {t[1].item():8.1f}  "
+              f"adjacency words {t[2].item():9.0f}  hops {o['hops'].double().mean().item():7.1f}", flush=True)

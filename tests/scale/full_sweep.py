@@ -19,7 +19,7 @@ ap.add_argument("--cpu-queries", type=int, default=2000)
 ap.add_argument("--out", default="gpurun_out/sweep_t2i10m.csv")
 ap.add_argument("--no-cpu", action="store_true")
 ap.add_argument("--builder", default="reference")
-ap.add_argument("--graph-cache", default="/tmp/r3_graph2.index")
+ap.add_argument("--graph-cache", default="/tmp/r4_graph.index")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scripts"))
@@ -30,15 +30,22 @@ impl = "ref" if oracle.have_ref() else "port"
 threads = min(oracle.max_threads(impl), bench.effective_cpus())
 hb = base.cpu().numpy(); ep, off, nbrs = idx.GetProjectionGraph(); hq = queries.cpu().numpy()
 cpu_L = {10, 20, 50, 60, 100, 200, 500, 1000, 2000}
-rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,kernel_cmps,vis_entries,hub_bitmap,grid,roofline_frac,"
-        "lds_exact_ms,lds_exact_cmps,lds_exact_roofline_frac,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
+rows = ["L_pq,qps,avg_cmps,mean_latency_ms,recall,avg_hops,visited_mode,kernel_cmps,screen,vis_entries,hub_bitmap,grid,rows_8bit,rows_f32,roofline_frac,"
+        "reference_bytes_rate_over_peak,lds_exact_ms,lds_exact_cmps,cpu_qps,cpu_threads,gpu_cpu_ids_identical"]
+tblock = torch.zeros((nq, 4), dtype=torch.int32, device="cuda")
+srow = idx.info("screen_row_bytes")
 ap_cpu = not args.no_cpu
 for L in bench.L_LIST:
     for _ in range(2): out = idx.SearchRoarGraphBatchDevice(queries, k, L)
     torch.cuda.synchronize()
     ms = idx.info("last_kernel_ns") / 1e6
     mode, ve, grid, hubf = idx.info("last_visited_mode"), idx.info("last_vis_entries"), idx.info("last_grid"), idx.info("last_hub_bitmap")
-    forgetful = idx.info("last_visited_forgetful")
+    forgetful, screen = idx.info("last_visited_forgetful"), idx.info("last_screen")
+    idx.SetTrafficCounters(tblock)  # the same plan once more under the counting instantiation
+    idx.SearchRoarGraphBatchDevice(queries, k, L); torch.cuda.synchronize()
+    idx.SetTrafficCounters(None)
+    tb = tblock.to(torch.float64).sum(dim=0)
+    impl_bytes = bench.implemented_bytes(tb[0].item(), tb[1].item(), tb[2].item(), nq, 200, srow, k)
     idx.set_option("visited_mode", 1)  # the on-chip table in its exact form (full sets spill to HBM): cmps must be the reference's
     for _ in range(2): sp = idx.SearchRoarGraphBatchDevice(queries, k, L)
     torch.cuda.synchronize()
@@ -60,8 +67,9 @@ for L in bench.L_LIST:
         gi = out["ids"][:m].cpu().numpy().view(np.uint32); gd = out["dists"][:m].cpu().numpy()
         same = f"{float(((gi == o['ids']).all(axis=1) & (gd == o['dists']).all(axis=1)).mean()):.4f}"
     rows.append(f"{L},{nq / ms * 1e3:.0f},{float(ex['cmps'].float().mean()):.1f},{ms / nq:.6f},{rec:.4f},"
-                f"{float(out['hops'].float().mean()):.2f},{('lds-forgetful' if forgetful else 'lds-exact') if mode == 1 else 'exact'},{float(out['cmps'].float().mean()):.1f},{ve},{hubf},{grid},"
-                f"{alg / (ms * 1e-3) / 8e12:.3f},{sp_ms:.3f},{float(sp['cmps'].float().mean()):.1f},{alg / (sp_ms * 1e-3) / 8e12:.3f},{cpu_qps},{threads if cpu_qps else ''},{same}")
+                f"{float(out['hops'].float().mean()):.2f},{('lds-forgetful' if forgetful else 'lds-exact') if mode == 1 else 'exact'},{float(out['cmps'].float().mean()):.1f},{screen},{ve},{hubf},{grid},"
+                f"{tb[0].item() / nq:.1f},{tb[1].item() / nq:.1f},{impl_bytes / (ms * 1e-3) / 8e12:.3f},"
+                f"{alg / (ms * 1e-3) / 8e12:.3f},{sp_ms:.3f},{float(sp['cmps'].float().mean()):.1f},{cpu_qps},{threads if cpu_qps else ''},{same}")
     print(rows[-1], flush=True)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
 open(args.out, "w").write("\n".join(rows) + "\n")

@@ -178,7 +178,7 @@ struct KnnBfParams {
 // TFLOP/s).  For the count to be the same in every wave each thread issues exactly JT + 1 loads per tile (slots past the tile and tiles
 // past the slice re-read a valid row into spare LDS), the rows' squared norms travel by LDS-DMA too, and nothing else in the loop is a
 // vector-memory operation: admitted rows are staged in LDS (ds_add_rtn + ds_write) and leave for the candidate lists every 32 tiles.
-template <int KS, int JT, int NBUF, int HCAP>
+template <int KS, int JT, int NBUF, int HCAP, bool IP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) knn_pass_bf16_kernel(const KnnBfParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -226,8 +226,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(af[ks]));
 #pragma unroll
     for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(thr[g]), "v"(eq[g]));
+    // byte offsets of this thread's slots from the tile's first row: inside the slice every source address is a UNIFORM tile base (scalar
+    // registers, scalar arithmetic) + one of these (the first form multiplied row x stride x KQ in 64 bits per lane and load: five
+    // quarter-rate multiplies per load, ~600 cycles per wave and tile beside 832 cycles of MFMA
+    // -- where the A fragments leave registers for it: the 512-d bucket keeps the first form)
+    constexpr bool FAST = KS <= 16;
+    uint32_t soff[FAST ? JT : 1];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j) soff[j] = (uint32_t)((u64)srow[j] * p.stride * KQ + scq[j]) * 16u;
+    }
+    const uint32_t noff = (uint32_t)((u64)lane * p.stride) * 4u;
+    const bool near = FAST && (u64)BT * p.stride * KQ * 16u < (1ull << 31);  // (uniform; the offsets above fit 32 bits)
     auto dma = [&](uint32_t b, u64 t0) {  // JT + 1 loads, always
         uint4 *buf = bufs + (size_t)b * JT * 512;
+        if constexpr (FAST) if (near && t0 + BT <= p.count) {
+            const unsigned char *tb = reinterpret_cast<const unsigned char *>(p.bb + (p.first + t0 * p.stride) * KQ);
+            const unsigned char *nb = reinterpret_cast<const unsigned char *>(p.bnorm + (p.first + t0 * p.stride));
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + soff[j]),
+                                                 (__attribute__((address_space(3))) void *)(buf + (size_t)j * 512 + wave * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nb + noff),
+                                             (__attribute__((address_space(3))) void *)(nrm + b * 64), 4, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             u64 si = t0 + srow[j];
@@ -250,7 +273,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const u64 e = skey[i];
             const uint32_t row = (uint32_t)e, qi = q0 + sql[i];
             const float dist = __uint_as_float((uint32_t)(e >> 32));
-            const float hi = dist + knn_eps(p.ea[qi], p.kq[qi], p.bnorm[row], p.kappa, p.ip);
+            const float hi = dist + knn_eps(p.ea[qi], p.kq[qi], p.bnorm[row], p.kappa, IP ? 1 : 0);
             const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
             if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
         }
@@ -265,9 +288,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         const u64 t0 = s0 + (u64)ti * BT;
         const uint32_t b = ti % NBUF;
+#if !defined(KNN_ABLATE_DMA)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
+#endif
+#if !defined(KNN_ABLATE_BARRIER)
         __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(KNN_ABLATE_DMA)
         dma((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
+#endif
         const uint4 *bufc = bufs + (size_t)b * JT * 512;
         f32x16 acc0, acc1;
 #pragma unroll
@@ -276,20 +305,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
         float bn0, bn1;
         lds_read2_f32(lds_addr(nrm + b * 64 + r), bn0, bn1);
-        u32x4 fa[2], fb[2];
-        lds_read2_b128<0>(a0, a1, fa[0], fb[0]);
+        // LD register buffers per operand stream: the reads of step ks + LD - 1 are issued before the MFMAs of step ks (one step ahead is 64
+        // cycles of MFMA cover for a ds_read_b128 that takes ~130 under eight waves' load: the second form of this loop waited ~65
+        // cycles per step; the 512-d bucket has no registers for a third buffer)
+        constexpr int LD = KS <= 16 ? 3 : 2;
+        u32x4 fa[LD], fb[LD];
+        static_for<0, LD - 1>([&](auto c) {
+            constexpr int i = decltype(c)::value;
+            if constexpr (i < KS) lds_read2_b128<i * 32>(a0, a1, fa[i], fb[i]);
+        });
         static_for<0, KS>([&](auto c) {
             constexpr int ks = decltype(c)::value;
-            if constexpr (ks + 1 < KS) {
-                lds_read2_b128<(ks + 1 < KS ? ks + 1 : 0) * 32>(a0, a1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-                lds_wait<2>(fa[ks & 1], fb[ks & 1]);
-            } else {
-                lds_wait<0>(fa[ks & 1], fb[ks & 1]);
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fa[ks & 1]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fb[ks & 1]), acc1, 0, 0, 0);
+            constexpr int nx = ks + LD - 1;
+            if constexpr (nx < KS) lds_read2_b128<(nx < KS ? nx : 0) * 32>(a0, a1, fa[nx % LD], fb[nx % LD]);
+            constexpr int later = (KS - 1 - ks) < (LD - 1) ? (KS - 1 - ks) : (LD - 1);  // read pairs issued after step ks's
+            lds_wait<2 * later>(fa[ks % LD], fb[ks % LD]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fa[ks % LD]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fb[ks % LD]), acc1, 0, 0, 0);
         });
         // epilogue: column (base row) = lane & 31 of each 32-wide half, row (query) in the register index
+        const bool cv_all = t0 + BT <= s1;  // (every tile but a slice's last: no per-column mask)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const u64 si = t0 + 32 * t + r;
@@ -297,31 +332,42 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const uint32_t row = (uint32_t)(p.first + (cv ? si : s1 - 1) * p.stride);
             const float bn = t ? bn1 : bn0;
             const float xn = __builtin_sqrtf(bn) * 1.0002f;
-            const float bl = p.ip ? 0.f : __builtin_fmaf(-p.kappa, bn, bn);  // L2: |x|^2 less its own part of eps
-            uint32_t hits = 0;
+            const float bl = IP ? 0.f : __builtin_fmaf(-p.kappa, bn, bn);  // L2: |x|^2 less its own part of eps
+            // lo = d^ - eps <= U (kq, the query's constant part of eps, sits in thr): one fma and one compare per element; the verdicts
+            // stay lane masks in scalar registers (the first form packed them into a per-lane word: 13 VALU instructions per element,
+            // sixteen per MFMA -- the epilogue, not the matrix cores, set the pace: profiles/r04_knn_counters.txt)
+            u64 hm[16], any = 0;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {  // lo = d^ - eps <= U  (kq, the query's constant part of eps, sits in thr)
+            for (int g = 0; g < 16; ++g) {
                 const float dot = t ? acc1[g] : acc0[g];
-                const float lo = __builtin_fmaf(-eq[g], xn, p.ip ? -dot : __builtin_fmaf(-2.f, dot, bl));
-                hits |= (cv && lo <= thr[g]) ? (1u << g) : 0u;
+                const float lo = IP ? -__builtin_fmaf(eq[g], xn, dot) : __builtin_fmaf(-eq[g], xn, __builtin_fmaf(-2.f, dot, bl));
+                hm[g] = __ballot(lo <= thr[g]);
+                any |= hm[g];
             }
-            if (__ballot(hits != 0)) {  // rare: ~k x ratio admissions per query and pass
+            if (!cv_all) any &= __ballot(cv);
+#if defined(KNN_ABLATE_EPILOGUE)
+            any = (any == 0x123456789ull) ? 1 : 0;
+#endif
+            if (any) {  // rare: ~k x ratio admissions per query and pass
                 bool spilled = false;
-                for (; hits; hits &= hits - 1) {
-                    const int g = __ffs((int)hits) - 1;
-                    const float dot = t ? acc1[g] : acc0[g];
-                    const uint32_t ql = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    const float dist = p.ip ? -dot : __builtin_fmaf(-2.f, dot, bn);
-                    const uint32_t at = lds_add_rtn(lds_addr(scnt), 1u);
-                    if (at < (uint32_t)HCAP) {
-                        lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
-                        lds_write_b16(lds_addr(sql + at), ql);
-                    } else {  // the staging block is full (the first pass admits every row): straight to the list
-                        const uint32_t qi = q0 + ql;
-                        const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, p.ip);
-                        const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
-                        if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
-                        spilled = true;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    if (hm[g] == 0) continue;  // uniform
+                    if (((hm[g] >> lane) & 1ull) && cv) {
+                        const float dot = t ? acc1[g] : acc0[g];
+                        const uint32_t ql = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
+                        const float dist = IP ? -dot : __builtin_fmaf(-2.f, dot, bn);
+                        const uint32_t at = lds_add_rtn(lds_addr(scnt), 1u);
+                        if (at < (uint32_t)HCAP) {
+                            lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
+                            lds_write_b16(lds_addr(sql + at), ql);
+                        } else {  // the staging block is full (the first pass admits every row): straight to the list
+                            const uint32_t qi = q0 + ql;
+                            const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, IP ? 1 : 0);
+                            const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
+                            if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
+                            spilled = true;
+                        }
                     }
                 }
                 if (__ballot(spilled)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see flush)
@@ -451,13 +497,17 @@ __global__ void __launch_bounds__(256) knn_rerank_kernel(const u64 *__restrict__
     }
 }
 
+template <int KS, int JT, int NBUF, int HCAP, bool IP>
+hipError_t launch_pass_m(const KnnBfParams &p, uint32_t grid, hipStream_t st) {
+    const size_t lds = (size_t)NBUF * JT * 512 * 16 + NBUF * 256 + (size_t)HCAP * 10 + 16;
+    hipError_t e = hipFuncSetAttribute((const void *)knn_pass_bf16_kernel<KS, JT, NBUF, HCAP, IP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((knn_pass_bf16_kernel<KS, JT, NBUF, HCAP, IP>), dim3(grid), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
 template <int KS, int JT, int NBUF, int HCAP>
 hipError_t launch_pass(const KnnBfParams &p, uint32_t grid, hipStream_t st) {
-    const size_t lds = (size_t)NBUF * JT * 512 * 16 + NBUF * 256 + (size_t)HCAP * 10 + 16;
-    hipError_t e = hipFuncSetAttribute((const void *)knn_pass_bf16_kernel<KS, JT, NBUF, HCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((knn_pass_bf16_kernel<KS, JT, NBUF, HCAP>), dim3(grid), dim3(512), lds, st, p);
-    return hipGetLastError();
+    return p.ip ? launch_pass_m<KS, JT, NBUF, HCAP, true>(p, grid, st) : launch_pass_m<KS, JT, NBUF, HCAP, false>(p, grid, st);
 }
 
 }  // namespace

@@ -127,12 +127,35 @@ template <int OFF>
 __device__ __forceinline__ void lds_read2_b128(uint32_t a0, uint32_t a1, u32x4 &f0, u32x4 &f1) {
     asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(f0), "=&v"(f1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
 }
+// LDS-DMA with the address split the way the hardware takes it: uniform 64-bit base in scalar registers + 32-bit per-lane offset; the
+// LDS side is M0 (uniform base; the lanes' 16 / 4 bytes follow each other from there).  Every LDS-DMA of the pass kernel goes through
+// these four, so no M0 value of the compiler's is alive across them.
+__device__ __forceinline__ void dma_b128(const void *base, uint32_t off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void *base, uint32_t off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma_b128_at(const void *src, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma_b32_at(const void *src, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(uint32_t a, u32x4 &f) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f) : "v"(a), "n"(OFF) : "memory");
+}
+template <int LEFT>
+__device__ __forceinline__ void lds_wait1(u32x4 &f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(LEFT) : "memory");
+}
 template <int LEFT>  // wait until at most LEFT LDS instructions of this wave are outstanding; the fragments become usable here
 __device__ __forceinline__ void lds_wait(u32x4 &f0, u32x4 &f1) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(LEFT) : "memory");
 }
-__device__ __forceinline__ void lds_read2_f32(uint32_t a, float &x0, float &x1) {  // a[0], a[32]
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a) : "memory");
+__device__ __forceinline__ void lds_read2_f32_nowait(uint32_t a, float &x0, float &x1) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128" : "=&v"(x0), "=&v"(x1) : "v"(a) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_add_rtn(uint32_t a, uint32_t v) {
     uint32_t old;
@@ -182,7 +205,7 @@ template <int KS, int JT, int NBUF, int HCAP, bool IP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) knn_pass_bf16_kernel(const KnnBfParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const uint32_t KQ = p.KQ;
+    constexpr uint32_t KQ = 2 * KS + 1;  // (= p.KQ: roar_knn_bf16_row_quads)
     uint4 *bufs = reinterpret_cast<uint4 *>(smem);                                       // [NBUF][JT * 512] quads
     float *nrm = reinterpret_cast<float *>(smem + (size_t)NBUF * JT * 512 * 16);          // [NBUF][64] squared norms of the tile's rows
     u64 *skey = reinterpret_cast<u64 *>(smem + (size_t)NBUF * JT * 512 * 16 + NBUF * 256);  // [HCAP] bits(d^) << 32 | row
@@ -212,57 +235,54 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         eq[g] = qi < p.nq ? p.ea[qi] : 0.f;
     }
     // where this thread's DMA slots of a tile come from: slot = j * 512 + tid -> (row of the tile, quad of the row); slots past the tile
-    // re-read its last row (into the spare end of the buffer)
-    uint32_t srow[JT], scq[JT];
+    // re-read its last row (into the spare end of the buffer).  Kept as ONE 32-bit byte offset from the tile's first row: inside the slice
+    // a source address is a UNIFORM tile base (scalar registers, scalar arithmetic) + that offset (the first form multiplied
+    // row x stride x KQ in 64 bits per lane and load: five quarter-rate multiplies per load, ~600 cycles per wave and tile).
+    // (the 512-d bucket, its A fragments half the register file, recomputes it per load: a spilled offset comes back by a scratch load, and
+    // the wait for THAT drains the LDS-DMA pipeline)
+    constexpr bool KEEP = KS <= 16;
+    const uint32_t rowstep = (uint32_t)(p.stride * KQ);
+    auto slot_off = [&](int j, uint32_t tid_) {
+        const uint32_t slot = (uint32_t)j * 512u + tid_;
+        return (std::min<uint32_t>(slot / KQ, BT - 1) * rowstep + slot % KQ) * 16u;
+    };
+    uint32_t soff[KEEP ? JT : 1];
+    if constexpr (KEEP) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const uint32_t slot = (uint32_t)j * 512u + (uint32_t)tid;
-        srow[j] = std::min<uint32_t>(slot / KQ, BT - 1);
-        scq[j] = slot % KQ;
+        for (int j = 0; j < JT; ++j) soff[j] = slot_off(j, (uint32_t)tid);
     }
+    const uint32_t noff = (uint32_t)((u64)lane * p.stride) * 4u;
+    const bool near = (u64)BT * p.stride * KQ * 16u < (1ull << 31);  // (uniform; the offsets above fit 32 bits)
     // everything loaded so far is in its registers before the pipeline starts: inside the loop the only vector-memory operations are the
     // LDS-DMA loads, and the compiler has no reason to wait for anything there (it would wait for ALL of them)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(af[ks]));
 #pragma unroll
     for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(thr[g]), "v"(eq[g]));
-    // byte offsets of this thread's slots from the tile's first row: inside the slice every source address is a UNIFORM tile base (scalar
-    // registers, scalar arithmetic) + one of these (the first form multiplied row x stride x KQ in 64 bits per lane and load: five
-    // quarter-rate multiplies per load, ~600 cycles per wave and tile beside 832 cycles of MFMA
-    // -- where the A fragments leave registers for it: the 512-d bucket keeps the first form)
-    constexpr bool FAST = KS <= 16;
-    uint32_t soff[FAST ? JT : 1];
-    if constexpr (FAST) {
-#pragma unroll
-        for (int j = 0; j < JT; ++j) soff[j] = (uint32_t)((u64)srow[j] * p.stride * KQ + scq[j]) * 16u;
-    }
-    const uint32_t noff = (uint32_t)((u64)lane * p.stride) * 4u;
-    const bool near = FAST && (u64)BT * p.stride * KQ * 16u < (1ull << 31);  // (uniform; the offsets above fit 32 bits)
     auto dma = [&](uint32_t b, u64 t0) {  // JT + 1 loads, always
-        uint4 *buf = bufs + (size_t)b * JT * 512;
-        if constexpr (FAST) if (near && t0 + BT <= p.count) {
+        const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_addr(bufs + (size_t)b * JT * 512 + wave * 64));
+        const uint32_t ln = lds_addr(nrm + b * 64);
+        if (near && t0 + BT <= p.count) {
             const unsigned char *tb = reinterpret_cast<const unsigned char *>(p.bb + (p.first + t0 * p.stride) * KQ);
             const unsigned char *nb = reinterpret_cast<const unsigned char *>(p.bnorm + (p.first + t0 * p.stride));
+            uint32_t tid_ = (uint32_t)tid;
+            if constexpr (!KEEP) asm volatile("" : "+v"(tid_));  // (recomputed HERE, every time: hoisted out of the loop it would be spilled)
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + soff[j]),
-                                                 (__attribute__((address_space(3))) void *)(buf + (size_t)j * 512 + wave * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nb + noff),
-                                             (__attribute__((address_space(3))) void *)(nrm + b * 64), 4, 0, 0);
+            for (int j = 0; j < JT; ++j) dma_b128(tb, KEEP ? soff[KEEP ? j : 0] : slot_off(j, tid_), lb + (uint32_t)j * 8192u);
+            dma_b32(nb, KEEP ? noff : (tid_ & 63u) * (uint32_t)p.stride * 4u, ln);
             return;
         }
+        // the slice's last tiles (and strides past 32-bit offsets): rows past the end re-read the last one (masked in the epilogue)
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            u64 si = t0 + srow[j];
-            si = si < p.count ? si : p.count - 1;  // (rows past the end re-read the last one: masked in the epilogue)
-            const uint4 *src = p.bb + (p.first + si * p.stride) * KQ + scq[j];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(buf + (size_t)j * 512 + wave * 64), 16, 0, 0);
+            const uint32_t slot = (uint32_t)j * 512u + (uint32_t)tid;
+            u64 si = t0 + std::min<uint32_t>(slot / KQ, BT - 1);
+            si = si < p.count ? si : p.count - 1;
+            dma_b128_at(p.bb + (p.first + si * p.stride) * KQ + slot % KQ, lb + (uint32_t)j * 8192u);
         }
         u64 si = t0 + (uint32_t)lane;
         si = si < p.count ? si : p.count - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.bnorm + (p.first + si * p.stride)),
-                                         (__attribute__((address_space(3))) void *)(nrm + b * 64), 4, 0, 0);  // (every wave: the same 256 bytes)
+        dma_b32_at(p.bnorm + (p.first + si * p.stride), ln);  // (every wave: the same 256 bytes)
     };
     auto flush = [&]() {  // staged admissions -> candidate lists (hi = d^ + eps), by the whole workgroup
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,95 +305,142 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const uint32_t ntiles = (uint32_t)((s1 - s0 + BT - 1) / BT);
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) dma((uint32_t)i, s0 + (u64)i * BT);
-    for (uint32_t ti = 0; ti < ntiles; ++ti) {
-        const u64 t0 = s0 + (u64)ti * BT;
-        const uint32_t b = ti % NBUF;
-#if !defined(KNN_ABLATE_DMA)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
+
+    // The verdicts of one 32 x 32 block of scores (column = base row = lane & 31, row = query in the register index): lo = d^ - eps <= U
+    // (kq, the query's constant part of eps, sits in thr) is one fma and one compare per element, and the verdicts stay lane masks in
+    // scalar registers (the first form packed them into a per-lane word: 13 VALU instructions per element, sixteen per MFMA -- the
+    // epilogue, not the matrix cores, set the pace: profiles/r04_knn_counters.txt).
+    auto verdict = [&](const f32x16 &acc, int g, float xn, float bl) -> u64 {
+        const float lo = IP ? -__builtin_fmaf(eq[g], xn, acc[g]) : __builtin_fmaf(-eq[g], xn, __builtin_fmaf(-2.f, acc[g], bl));
+#if defined(KNN_ABL_NOVERDICT)
+        return g == 0 ? __ballot(acc[0] == 12345.678f) : 0;
 #endif
-#if !defined(KNN_ABLATE_BARRIER)
-        __builtin_amdgcn_s_barrier();
-#endif
-#if !defined(KNN_ABLATE_DMA)
-        dma((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
-#endif
-        const uint4 *bufc = bufs + (size_t)b * JT * 512;
-        f32x16 acc0, acc1;
+        return __ballot(lo <= thr[g]);
+    };
+    // rare (~k x ratio admissions per query and pass): the admitted elements of one block -> the staging list
+    auto admit = [&](const f32x16 &acc, const u64 (&hm)[16], u64 tile0, int half, float bn) {
+        const u64 si = tile0 + 32 * half + r;
+        const bool cv = si < s1;
+        const uint32_t row = (uint32_t)(p.first + (cv ? si : s1 - 1) * p.stride);
+        bool spilled = false;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc0[g] = 0.f, acc1[g] = 0.f;
-        // B fragments: rows r and 32 + r of the tile, quad 2 ks + h; the reads of step ks + 1 are issued before the MFMAs of step ks
-        const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
-        float bn0, bn1;
-        lds_read2_f32(lds_addr(nrm + b * 64 + r), bn0, bn1);
-        // LD register buffers per operand stream: the reads of step ks + LD - 1 are issued before the MFMAs of step ks (one step ahead is 64
-        // cycles of MFMA cover for a ds_read_b128 that takes ~130 under eight waves' load: the second form of this loop waited ~65
-        // cycles per step; the 512-d bucket has no registers for a third buffer)
-        constexpr int LD = KS <= 16 ? 3 : 2;
-        u32x4 fa[LD], fb[LD];
+        for (int g = 0; g < 16; ++g) {
+            if (hm[g] == 0) continue;  // uniform
+            if (((hm[g] >> lane) & 1ull) && cv) {
+                const float dot = acc[g];
+                const uint32_t ql = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
+                const float dist = IP ? -dot : __builtin_fmaf(-2.f, dot, bn);
+                const uint32_t at = lds_add_rtn(lds_addr(scnt), 1u);
+                if (at < (uint32_t)HCAP) {
+                    lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
+                    lds_write_b16(lds_addr(sql + at), ql);
+                } else {  // the staging block is full (the first pass admits every row): straight to the list
+                    const uint32_t qi = q0 + ql;
+                    const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, IP ? 1 : 0);
+                    const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
+                    if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
+                    spilled = true;
+                }
+            }
+        }
+        if (__ballot(spilled)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see flush)
+    };
+    // 13 (K / 16) MFMAs of one block, B fragments read LD - 1 steps ahead from LDS address `a` (quad 2 ks + h of the lane's row), and BETWEEN
+    // them the sixteen verdicts of the block finished before (`old`): an MFMA occupies the matrix core for 32 cycles and the wave's
+    // issue slot for 4, the verdicts are independent of it -- written in this order they run under the MFMAs instead of after them
+    // (second form of the loop: all MFMAs of a tile, then all verdicts, both waves of a SIMD in step behind the tile's barrier: 36 % MFMA
+    // busy, profiles/r04_knn_counters.txt)
+    constexpr int LD = KS <= 16 ? 3 : 2;
+    auto block = [&](f32x16 &acc, uint32_t a, const f32x16 &old, float xn, float bl, u64 (&hm)[16]) {
+        u32x4 f[LD];
         static_for<0, LD - 1>([&](auto c) {
             constexpr int i = decltype(c)::value;
-            if constexpr (i < KS) lds_read2_b128<i * 32>(a0, a1, fa[i], fb[i]);
+            if constexpr (i < KS) lds_read_b128<i * 32>(a, f[i]);
         });
         static_for<0, KS>([&](auto c) {
             constexpr int ks = decltype(c)::value;
             constexpr int nx = ks + LD - 1;
-            if constexpr (nx < KS) lds_read2_b128<(nx < KS ? nx : 0) * 32>(a0, a1, fa[nx % LD], fb[nx % LD]);
-            constexpr int later = (KS - 1 - ks) < (LD - 1) ? (KS - 1 - ks) : (LD - 1);  // read pairs issued after step ks's
-            lds_wait<2 * later>(fa[ks % LD], fb[ks % LD]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fa[ks % LD]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, fb[ks % LD]), acc1, 0, 0, 0);
+            if constexpr (nx < KS) lds_read_b128<(nx < KS ? nx : 0) * 32>(a, f[nx % LD]);
+            constexpr int later = (KS - 1 - ks) < (LD - 1) ? (KS - 1 - ks) : (LD - 1);  // reads issued after step ks's
+            lds_wait1<later>(f[ks % LD]);
+            if constexpr (ks == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) z[g] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, f[ks % LD]), z, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, f[ks % LD]), acc, 0, 0, 0);
+            }
+            // verdicts g with g * KS / 16 == ks: sixteen spread over the KS steps
+            static_for<0, 16>([&](auto cg) {
+                constexpr int g = decltype(cg)::value;
+                if constexpr ((g * KS) / 16 == ks) hm[g] = verdict(old, g, xn, bl);
+            });
         });
-        // epilogue: column (base row) = lane & 31 of each 32-wide half, row (query) in the register index
-        const bool cv_all = t0 + BT <= s1;  // (every tile but a slice's last: no per-column mask)
+    };
+    // (the hardware's square root, 1 ulp, of a squared norm kept out of the range it flushes: xn stays >= |x_r|, which is all the bound
+    // asks of it -- the 15-instruction correctly rounded sqrt twice per tile was a tenth of the loop's vector instructions)
+    auto norm_terms = [&](float bn, float &xn, float &bl) {
+        xn = __builtin_amdgcn_sqrtf(__builtin_fmaxf(bn, 1e-30f)) * 1.0002f;
+        bl = IP ? 0.f : __builtin_fmaf(-p.kappa, bn, bn);  // L2: |x|^2 less its own part of eps
+    };
+
+    f32x16 acc0, acc1;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const u64 si = t0 + 32 * t + r;
-            const bool cv = si < s1;
-            const uint32_t row = (uint32_t)(p.first + (cv ? si : s1 - 1) * p.stride);
-            const float bn = t ? bn1 : bn0;
-            const float xn = __builtin_sqrtf(bn) * 1.0002f;
-            const float bl = IP ? 0.f : __builtin_fmaf(-p.kappa, bn, bn);  // L2: |x|^2 less its own part of eps
-            // lo = d^ - eps <= U (kq, the query's constant part of eps, sits in thr): one fma and one compare per element; the verdicts
-            // stay lane masks in scalar registers (the first form packed them into a per-lane word: 13 VALU instructions per element,
-            // sixteen per MFMA -- the epilogue, not the matrix cores, set the pace: profiles/r04_knn_counters.txt)
-            u64 hm[16], any = 0;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float dot = t ? acc1[g] : acc0[g];
-                const float lo = IP ? -__builtin_fmaf(eq[g], xn, dot) : __builtin_fmaf(-eq[g], xn, __builtin_fmaf(-2.f, dot, bl));
-                hm[g] = __ballot(lo <= thr[g]);
-                any |= hm[g];
-            }
-            if (!cv_all) any &= __ballot(cv);
-#if defined(KNN_ABLATE_EPILOGUE)
-            any = (any == 0x123456789ull) ? 1 : 0;
+    for (int g = 0; g < 16; ++g) acc0[g] = 0.f, acc1[g] = 0.f;
+    float bn1p = 0.f;  // the previous tile's second block: its rows' squared norms
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        const u64 t0 = s0 + (u64)ti * BT;
+        const uint32_t b = ti % NBUF;
+#if !defined(KNN_ABL_NODMA)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
 #endif
-            if (any) {  // rare: ~k x ratio admissions per query and pass
-                bool spilled = false;
+#if !defined(KNN_ABL_NOBAR)
+        __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(KNN_ABL_NODMA)
+        dma((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
+#endif
+        const uint4 *bufc = bufs + (size_t)b * JT * 512;
+        const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
+        float bn0, bn1;  // issued here, first used a block later: LDS operations complete in order, the block's counted waits cover them
+        lds_read2_f32_nowait(lds_addr(nrm + b * 64 + r), bn0, bn1);
+        u64 hm[16];
+        float xn, bl;
+        // rows 0..31 of this tile, under them the verdicts of rows 32..63 of the tile before (a whole tile: no column mask)
+        norm_terms(bn1p, xn, bl);
+        block(acc0, a0, acc1, xn, bl, hm);
+        {
+            u64 any = 0;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    if (hm[g] == 0) continue;  // uniform
-                    if (((hm[g] >> lane) & 1ull) && cv) {
-                        const float dot = t ? acc1[g] : acc0[g];
-                        const uint32_t ql = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
-                        const float dist = IP ? -dot : __builtin_fmaf(-2.f, dot, bn);
-                        const uint32_t at = lds_add_rtn(lds_addr(scnt), 1u);
-                        if (at < (uint32_t)HCAP) {
-                            lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
-                            lds_write_b16(lds_addr(sql + at), ql);
-                        } else {  // the staging block is full (the first pass admits every row): straight to the list
-                            const uint32_t qi = q0 + ql;
-                            const float hi = dist + knn_eps(eq[g], p.kq[qi], bn, p.kappa, IP ? 1 : 0);
-                            const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
-                            if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;
-                            spilled = true;
-                        }
-                    }
-                }
-                if (__ballot(spilled)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see flush)
-            }
+            for (int g = 0; g < 16; ++g) any |= hm[g];
+            if (ti == 0) any = 0;
+            if (any) admit(acc1, hm, t0 - BT, 1, bn1p);
         }
-        if ((ti & 31u) == 31u || ti + 1 == ntiles) flush();
+        // rows 32..63, under them the verdicts of rows 0..31
+        asm volatile("" : "+v"(bn0), "+v"(bn1));  // (usable from here: behind the first block's waits)
+        norm_terms(bn0, xn, bl);
+        block(acc1, a1, acc0, xn, bl, hm);
+        {
+            u64 any = 0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) any |= hm[g];
+            if (t0 + 32 > s1) any &= __ballot(t0 + r < s1);
+            if (any) admit(acc0, hm, t0, 0, bn0);
+        }
+        bn1p = bn1;
+        if ((ti & 31u) == 31u) flush();
+    }
+    {  // the last tile's second block
+        const u64 t0 = s0 + (u64)(ntiles - 1) * BT;
+        float xn, bl;
+        norm_terms(bn1p, xn, bl);
+        u64 hm[16], any = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) hm[g] = verdict(acc1, g, xn, bl), any |= hm[g];
+        any &= __ballot(t0 + 32 + r < s1);
+        if (any) admit(acc1, hm, t0, 1, bn1p);
+        flush();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the look-ahead loads past the slice must land before the LDS goes away)
 }

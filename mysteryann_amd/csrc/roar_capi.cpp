@@ -723,10 +723,15 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     uint32_t off = 0;
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
+    // candidate ids / keys of one adjacency round trip: three 64-word chunks of a row -- two when no row has a third (stride <= 128 words:
+    // the benchmark graphs), one for stride 64.  768 bytes less per query is a workgroup more per CU at every other L_pq of a long pool
+    // (the LDS is handed out in 1 280-byte blocks, below), and long pools live on resident workgroups: T2I-10M, L_pq = 1 000, 2 048 tags,
+    // nine per CU 36.2 ms -> ten per CU (profiles/r04_long_pools_lds.txt).
+    const uint32_t trip = (use_hub || bipartite || idx->adj_stride > 128u) ? 192u : idx->adj_stride > 64u ? 128u : 64u;
     p.off_ck = off;
-    off += bp_wg ? 8 * 64 * 8 : 8 * 192;   // eight waves x 64 keys in the workgroup form; else one adjacency round trip (3 x 64)
+    off += bp_wg ? 8 * 64 * 8 : 8 * trip;   // eight waves x 64 keys in the workgroup form; else one adjacency round trip
     p.off_cid = off;
-    off += bp_wg ? 4 * 64 * 8 : 4 * 192;
+    off += bp_wg ? 4 * 64 * 8 : 4 * trip;
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
     if (p.screen) off += round_up(idx->dim_pad, 16);  // the query's 8-bit codes (screen8i_pass)
@@ -1906,13 +1911,25 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
                 if (!b || c.ms < b->ms) b = &c;
             return b;
         };
-        // stage 2: one step further in the direction that won (a smaller table buys resident workgroups, a bigger one forgets less)
+        // stage 2: further in the direction that won, while it keeps winning (a smaller table buys resident workgroups -- a long pool
+        // leaves room for nine to twelve per CU and every 1 280 bytes count -- a bigger one forgets less), then the 3 x 2^k size next to
+        // the winner
         if (!hard_error && entries_free) {
             const Cand *b = best_of();
             if (b && b->mode == ROAR_VISITED_LDS) {
                 const int sc = screen_free ? b->screen : -1;
-                if (b->entries <= 4096) try_pick(sc, ROAR_VISITED_LDS, 2048);
-                else if (b->entries >= 8192) try_pick(sc, ROAR_VISITED_LDS, 16384);
+                if (b->entries <= 4096) {
+                    for (uint32_t e = 2048; e >= 1024 && !hard_error; e >>= 1) {
+                        const Cand *c = try_pick(sc, ROAR_VISITED_LDS, e);
+                        b = best_of();
+                        if (!c || !b || b->entries != c->entries || b->mode != ROAR_VISITED_LDS) break;  // (did not win: stop here)
+                    }
+                } else if (b->entries >= 8192) {
+                    try_pick(sc, ROAR_VISITED_LDS, 16384);
+                }
+                b = best_of();
+                if (!hard_error && b && b->mode == ROAR_VISITED_LDS && L >= 256 && b->entries >= 1024 && b->entries <= 4096)
+                    try_pick(sc, ROAR_VISITED_LDS, b->entries + b->entries / 2);
             }
         }
         // stage 3: HBM epoch tags instead of the table -- only worth a look (and the tag lists' memory) once the pool is long

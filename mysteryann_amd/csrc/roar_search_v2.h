@@ -1008,8 +1008,9 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
             if (wid == 0) {
                 if (PROF) n_surv += nsurv;
-                for (uint32_t b = 0; b < nsurv; b += 64) {
-                    const uint32_t cnt = (nsurv - b < 64u) ? nsurv - b : 64u;
+                const uint32_t ns = uni(nsurv);  // (it came through LDS: said to be uniform, the loop is a scalar one)
+                for (uint32_t b = 0; b < ns; b += 64) {
+                    const uint32_t cnt = (ns - b < 64u) ? ns - b : 64u;
                     if constexpr (RP) merge_regpool(pk, psize, ck + b, cnt, L, pool, lane);
                     else merge_candidates(pool, ck + b, cnt, L, psize, cur, lane);
                 }

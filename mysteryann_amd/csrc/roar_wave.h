@@ -202,86 +202,112 @@ __device__ __forceinline__ void score_candidates(const float *__restrict__ base,
 // NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of m <= 64 candidates at once.
 // Sequential inserts keep the top-L of everything seen; so does this merge, entry for entry.
 // Duplicate (distance, id) pairs are dropped exactly as the binary-search probe does (:161-162).
-__device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m, uint32_t L, uint32_t &psize,
+//
+// A hop of a long pool spends a third of its time here (T2I-10M, L_pq = 1 000: 6 000 of 17 500 cycles, profiles/r04_long_pools_phases.txt),
+// and that time is INSTRUCTIONS, not LDS latency: a wave-wide instruction costs its four cycles whether it moves one survivor or
+// sixty-four.  So: (1) the lower bounds start from 64 splitters read once (every (psize / 64)-th entry; a ballot per survivor names its
+// segment) and finish with log2(psize / 64) per-lane probes instead of log2(psize); (2) the pool is shifted SEGMENT by segment -- the
+// entries between two survivors' landing points all move by the same amount, so a 64-entry chunk is a read, an add and a write
+// (the first form recomputed every entry's shift from ballots over the survivors: ~75 instructions per chunk).
+__device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m_, uint32_t L_, uint32_t &psize,
                                                  uint32_t &cur, int lane) {
     const u64 FLAG = 1ull;
+    // Everything that steers a loop or a branch here is the same in every lane; said so explicitly (readfirstlane), it lives in scalar
+    // registers and the loops are scalar loops -- left to the compiler's divergence analysis, pool sizes that passed through LDS or
+    // through per-lane arithmetic were vector values and every `if` below a save / mask / restore of EXEC.
+    const uint32_t m = uni(m_), L = uni(L_), P = uni(psize), Pm1 = P ? P - 1u : 0u;
     bool valid = (uint32_t)lane < m;
-    u64 key = valid ? ck[lane] : ~0ull;
-    if (psize == L) {  // neighbor.h:151-153
+    u64 key = ck[(uint32_t)lane < m ? lane : 0];
+    key = valid ? key : ~0ull;
+    if (P == L) {  // neighbor.h:151-153
         const u64 last = pool[L - 1] & ~FLAG;
-        valid = valid && key < last;
+        valid = valid & (key < last);
     }
-    if (__ballot(valid) == 0) return;
+    const u64 vm0 = __ballot(valid);
+    if (vm0 == 0) return;
     // lower bound of key among the (flag-masked) pool keys
-    uint32_t lo = 0;
+    uint32_t lo = 0, len = P, span = P;  // (span: the longest range any lane still has to search)
+    if (P > 128u) {
+        // segment l = entries [l step, (l + 1) step) cut at P; its splitter = its last entry (segments past the end repeat the pool's last)
+        const uint32_t step = (P + 63u) >> 6;
+        const uint32_t e_l = ((uint32_t)(lane + 1) * step < P ? (uint32_t)(lane + 1) * step : P) - 1u;
+        const u64 spl = pool[e_l] & ~FLAG;
+        uint32_t seg = 0;
+        for (u64 it = vm0; it; it &= it - 1) {
+            const int j = __ffsll((long long)it) - 1;
+            const u64 kj = lane_u64(key, j);
+            const uint32_t below = (uint32_t)__popcll(__ballot(spl < kj));  // segments that lie wholly below kj
+            seg = (lane == j) ? below : seg;
+        }
+        lo = seg * step < P ? seg * step : P;
+        len = P - lo < step ? P - lo : step;
+        span = step;
+    }
     {
-        uint32_t len = psize;
-        const int iters = 32 - __builtin_clz(psize);  // psize >= 1
-        for (int it = 0; it < iters; ++it) {
-            if (len > 0) {
-                const uint32_t half = len >> 1, mid = lo + half;
-                const bool less = (pool[mid] & ~FLAG) < key;
-                lo = less ? mid + 1 : lo;
-                len = less ? len - half - 1 : half;
-            }
+        const int iters = span ? 32 - __builtin_clz(span) : 0;
+        for (int it = 0; it < iters; ++it) {  // (branch-free: a lane that is done probes its own `lo` again, cut to the pool, and ignores it)
+            const uint32_t half = len >> 1, mid = lo + half;
+            const u64 e = pool[mid < P ? mid : Pm1] & ~FLAG;
+            const bool less = (len > 0u) & (e < key);
+            lo = less ? mid + 1u : lo;
+            len = less ? len - half - 1u : half;
         }
     }
-    if (valid && lo < psize && (pool[lo] & ~FLAG) == key) valid = false;  // already in the pool
+    {
+        const u64 e = pool[lo < P ? lo : Pm1] & ~FLAG;
+        valid = valid & !((lo < P) & (e == key));  // already in the pool
+    }
     // rank among the surviving candidates; a later lane with an equal key is a duplicate
     uint32_t r = 0;
-    for (u64 it = __ballot(valid); it;) {
+    for (u64 it = __ballot(valid); it; it &= it - 1) {
         const int j = __ffsll((long long)it) - 1;
-        it &= it - 1;
-        if (!((__ballot(valid) >> j) & 1)) continue;
+        if (!((__ballot(valid) >> j) & 1ull)) continue;  // (uniform: j was a copy of an earlier key)
         const u64 kj = lane_u64(key, j);
-        if (valid && j != lane) {
-            if (kj < key) r++;
-            else if (kj == key && j < lane) valid = false;
-        }
+        const bool other = valid & (lane != j);
+        r += (other & (kj < key)) ? 1u : 0u;
+        valid = valid & !(other & (kj == key) & (j < lane));
     }
     const u64 vm = __ballot(valid);
     if (vm == 0) return;
     const uint32_t s = (uint32_t)__popcll(vm);
-    const int l0 = __ffsll((long long)__ballot(valid && r == 0)) - 1;
-    const uint32_t pmin = lane_u32(lo, l0);
-    // Shift pool[pmin, psize) right: the entry at index i moves up by the number of survivors whose lower bound
-    // is <= i.  64-entry chunks, top chunk first, four chunks read before the first is written back: the LDS executes
-    // a wave's instructions in order, a lower chunk's reads never overlap an upper chunk's (higher) write range, and
-    // a lower chunk's writes come after the upper chunk's reads in program order -- so no wait is needed in between.
-    const uint32_t slo = valid ? lo : 0xFFFFFFFFu;
-    for (uint32_t hi = psize; hi > pmin;) {
-        u64 e[4];
-        uint32_t dst[4];
-        bool act[4];
+    // Shift, top segment first: the entries from the rank-t survivor's lower bound up to the next survivor's (the pool's end for the
+    // last one) move up by t + 1.  64-entry chunks, top chunk first, up to four chunks read before the first is written back: the LDS
+    // executes a wave's instructions in order, a lower chunk's reads never overlap an upper chunk's (higher) write range, and a lower
+    // chunk's writes come after the upper chunk's reads in program order -- so no wait is needed in between.
+    uint32_t hi = P;
+    for (uint32_t t = s; t-- > 0;) {
+        const int l = __ffsll((long long)__ballot(valid & (r == t))) - 1;
+        const uint32_t seg_lo = lane_u32(lo, l), sh = t + 1u;
+        for (uint32_t top = hi; top > seg_lo;) {
+            const uint32_t left = top - seg_lo;
+            if (left >= 256u && top + sh <= L) {  // four whole chunks that stay inside the pool: no lane has anything to decide
+                u64 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            act[u] = false;
-            e[u] = 0ull;
-            dst[u] = 0u;
-            if (hi > pmin) {  // uniform
-                const uint32_t lo_c = (hi - pmin > 64u) ? hi - 64u : pmin;
+                for (int u = 0; u < 4; ++u) e[u] = pool[top - 64u * (uint32_t)(u + 1) + (uint32_t)lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pool[top - 64u * (uint32_t)(u + 1) + (uint32_t)lane + sh] = e[u];
+                top -= 256u;
+            } else if (left >= 64u && top + sh <= L) {
+                const u64 e = pool[top - 64u + (uint32_t)lane];
+                pool[top - 64u + (uint32_t)lane + sh] = e;
+                top -= 64u;
+            } else {  // the chunk at the pool's end when it is full (entries pushed past L_pq are dropped) and the segment's last, partial one
+                const uint32_t lo_c = left > 64u ? top - 64u : seg_lo;
                 const uint32_t kidx = lo_c + (uint32_t)lane;
-                const bool a = kidx < hi;
-                if (a) e[u] = pool[kidx];
-                uint32_t shift = (uint32_t)__popcll(__ballot(slo <= lo_c));
-                for (u64 it = __ballot(slo > lo_c && slo < hi); it;) {  // survivors landing inside this chunk
-                    const int j = __ffsll((long long)it) - 1;
-                    it &= it - 1;
-                    shift += (lane_u32(slo, j) <= kidx) ? 1u : 0u;
-                }
-                dst[u] = kidx + shift;
-                act[u] = a && dst[u] < L;
-                hi = lo_c;
+                const bool a = kidx < top;
+                const u64 e = pool[a ? kidx : lo_c];
+                if (a & (kidx + sh < L)) pool[kidx + sh] = e;
+                top = lo_c;
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (act[u]) pool[dst[u]] = e[u];
+        hi = seg_lo;
     }
+    const uint32_t pmin = hi;  // the rank-0 survivor's lower bound
     wave_sync();
     if (valid && lo + r < L) pool[lo + r] = key;
-    psize = (psize + s < L) ? psize + s : L;
-    cur = cur < pmin ? cur : pmin;  // neighbor.h:180-182
+    psize = (P + s < L) ? P + s : L;
+    const uint32_t c = uni(cur);
+    cur = c < pmin ? c : pmin;  // neighbor.h:180-182
     wave_sync();
 }
 

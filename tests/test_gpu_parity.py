@@ -736,8 +736,8 @@ def test_exact_knn_query_block_larger_than_one_launch(built_lib):
 def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
     """Default policy without a measurement (option calibrate = 0, plan_search): the on-chip tag table below L_pq = 1536, HBM epoch
     tags beyond; a dense graph (average degree x row bytes >= 24 x 800) takes the hub-bitmap form from L_pq = 100.  With the
-    calibration (default) the visited form is whatever was measured fastest -- and the hub rule stands.  All give the
-    reference's results."""
+    calibration (default) the visited form and the screen are whatever was measured fastest, and the hub rule stands for what it is: a
+    rule about launches WITHOUT the screen (with it no graph counts as dense).  All give the reference's results."""
     import oracle
     from mysteryann_amd import index as mi
 
@@ -756,8 +756,10 @@ def test_auto_visited_mode_switches_with_pool_length(golden_dir, built_lib):
                 idx.set_option("hub_mode", hub_mode)
                 for L, want_mode, want_hub in cases:
                     r = idx.SearchRoarGraphBatch(q, K, L)
-                    assert idx.info("last_hub_bitmap") == want_hub, (maxdeg, hub_mode, L)
+                    assert idx.info("last_hub_bitmap") == (0 if idx.info("last_screen") else want_hub), (maxdeg, hub_mode, L)
                     assert idx.info("last_plan_calibrated") == calibrate
+                    if not calibrate:
+                        assert idx.info("last_screen") == 0  # (rows under 768 bytes: off by default)
                     if not calibrate:
                         assert idx.info("last_visited_mode") == want_mode, (maxdeg, hub_mode, L)
                     o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 0)
@@ -1514,7 +1516,8 @@ def test_every_failed_device_allocation_is_reported_and_leaks_nothing(built_lib)
                 left = lib.roar_debug_fail_device_alloc_at(0)
             torch.cuda.synchronize()
             frees.append(torch.cuda.mem_get_info()[0])
-        assert abs(frees[1] - frees[0]) <= (4 << 20), (nth, frees[0] - frees[1])
+        # (one-sided: the second run may also find MORE free memory than the first -- the runtime gives a scratch arena back -- a leak cannot)
+        assert frees[0] - frees[1] <= (4 << 20), (nth, frees[0] - frees[1])
         assert free0 - frees[1] <= (256 << 20), (nth, free0 - frees[1])
         if left > 0:  # the scenario made fewer than nth allocations: every one of them has been failed once
             absorbed -= 1

@@ -23,10 +23,13 @@
 //      sorted by (distance, id).  The result is the exact top k under the reference's own arithmetic, whatever the bf16 pass did.
 //
 // GEMM tile: a workgroup of 8 waves owns 256 queries (wave w: 32 of them, its A fragments -- 13 x 4 VGPRs at D = 200 -- stay in
-// REGISTERS for the whole slice) and walks a slice of the sample in tiles of 64 base rows, double-buffered in LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers); per tile and wave 2 x K/16 MFMAs of 32x32x16, then 32 compares against the
-// per-query admission thresholds (16 registers) and a rare append.  1-D grid, query tile fastest: the workgroups that run together
-// stream the same slice (L2 / Infinity Cache), every base row leaves HBM about once per pass.
+// REGISTERS for the whole slice) and walks a slice of the sample in tiles of 64 base rows, NBUF tiles deep in LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, uniform tile base + 32-bit lane offset).  Per tile and wave two blocks of 32 rows:
+// K/16 MFMAs of 32x32x16 each, and between a block's MFMAs the 16 verdicts (one fma, one compare: a lane mask in scalar registers)
+// of the block finished before; admitted elements (rare) are staged in LDS.  1-D grid, query tile fastest: the workgroups that run
+// together stream the same slice (L2 / Infinity Cache), every base row leaves HBM about once per pass.
+// Measured (profiles/r04_knn_kernel_stats.txt, r04_knn_counters.txt, r04_mfma_probe.txt): last pass 0.39 of the bf16 peak, MFMA
+// busy 0.42; a loop of this shape with nothing but the MFMAs, the LDS reads and the verdicts reaches 0.72.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -123,10 +126,6 @@ __device__ __forceinline__ float knn_eps(float ea, float kq, float bn, float kap
 // draining the look-ahead loads the pipeline lives on.  The waits these need (lgkmcnt) are written out with them.
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p; }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void lds_read2_b128(uint32_t a0, uint32_t a1, u32x4 &f0, u32x4 &f1) {
-    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(f0), "=&v"(f1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
-}
 // LDS-DMA with the address split the way the hardware takes it: uniform 64-bit base in scalar registers + 32-bit per-lane offset; the
 // LDS side is M0 (uniform base; the lanes' 16 / 4 bytes follow each other from there).  Every LDS-DMA of the pass kernel goes through
 // these four, so no M0 value of the compiler's is alive across them.
@@ -149,10 +148,6 @@ __device__ __forceinline__ void lds_read_b128(uint32_t a, u32x4 &f) {
 template <int LEFT>
 __device__ __forceinline__ void lds_wait1(u32x4 &f) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(LEFT) : "memory");
-}
-template <int LEFT>  // wait until at most LEFT LDS instructions of this wave are outstanding; the fragments become usable here
-__device__ __forceinline__ void lds_wait(u32x4 &f0, u32x4 &f1) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(LEFT) : "memory");
 }
 __device__ __forceinline__ void lds_read2_f32_nowait(uint32_t a, float &x0, float &x1) {
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128" : "=&v"(x0), "=&v"(x1) : "v"(a) : "memory");
@@ -312,9 +307,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // epilogue, not the matrix cores, set the pace: profiles/r04_knn_counters.txt).
     auto verdict = [&](const f32x16 &acc, int g, float xn, float bl) -> u64 {
         const float lo = IP ? -__builtin_fmaf(eq[g], xn, acc[g]) : __builtin_fmaf(-eq[g], xn, __builtin_fmaf(-2.f, acc[g], bl));
-#if defined(KNN_ABL_NOVERDICT)
-        return g == 0 ? __ballot(acc[0] == 12345.678f) : 0;
-#endif
         return __ballot(lo <= thr[g]);
     };
     // rare (~k x ratio admissions per query and pass): the admitted elements of one block -> the staging list
@@ -392,15 +384,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         const u64 t0 = s0 + (u64)ti * BT;
         const uint32_t b = ti % NBUF;
-#if !defined(KNN_ABL_NODMA)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
-#endif
-#if !defined(KNN_ABL_NOBAR)
         __builtin_amdgcn_s_barrier();
-#endif
-#if !defined(KNN_ABL_NODMA)
         dma((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
-#endif
         const uint4 *bufc = bufs + (size_t)b * JT * 512;
         const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
         float bn0, bn1;  // issued here, first used a block later: LDS operations complete in order, the block's counted waits cover them

@@ -341,11 +341,15 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    on sets whose scores are bunched within the bound's slack it passes nearly everything and costs a second
  *                    dependent round trip for nothing), 2 = on wherever there is a kernel
  *   "calibrate"      1 (default): what no option fixes -- screen on / off, visited form, table size -- is MEASURED on the loaded index:
- *                    the first search of a (L_pq band, batch-size band, grid cap) times 5-8 candidate plans on the first (at most
+ *                    the first search of a (L_pq band, batch-size band, grid cap) times 5-10 candidate plans (tag tables from 16 384
+ *                    down to 1 024 tags and the 3 x 2^k sizes between them, HBM tags for long pools) on the first (at most
  *                    12 288) queries of that call, results into scratch buffers, and keeps the fastest for the launches that follow
  *                    (that call synchronises its stream; results never depend on the plan; ROAR_LOG_CALIBRATION=1 in the environment
  *                    prints every decision); 0: fixed defaults (screen on for rows of 768 bytes and more, the on-chip table with
  *                    4 096 / 8 192 tags up to L_pq = 1 536, HBM tags beyond); 2: forget what was measured so far
+ *   "knn_mode"       roar_exact_knn(_device): 0 (default) bf16 MFMA screen with a rigorous per-row bound + exact f32 re-rank in the
+ *                    reference's summation order (csrc/roar_knn_bf16.hip; it hands over to form 1 when the bound cannot be claimed),
+ *                    1 every score by f32 MFMA (csrc/roar_knn.hip)
  *   "profile_phases" 1: instrumented kernel (200-d inner-product and 128-d L2 shapes), see roar_last_profile
  *   "bipartite_seed" seed of the entry-point generator of roar_search_bipartite_batch(init_ids = NULL)
  *   "combine_single_queries"  1 (default): roar_search_batch calls with nq = 1 that arrive from several host
@@ -357,7 +361,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
  *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "screen_row_bytes" (bytes per
  *   row of the 8-bit screening copy at this dimension), "last_visited_forgetful", "last_plan_calibrated" (1 if the most recent search ran a measured plan),
- *   "calibrations" (launch kinds measured so far), "last_kernel_ns"
+ *   "calibrations" (launch kinds measured so far), "last_knn_bf16" (1 if the most recent exact kNN call ran the bf16-screened form), "last_knn_rerank_rows" (rows it scored on f32), "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */
 int roar_set_option(roar_index *idx, const char *key, int64_t value);

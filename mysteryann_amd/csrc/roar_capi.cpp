@@ -154,6 +154,7 @@ struct roar_index {
         uint64_t key;
         int screen, mode;
         uint32_t entries;
+        int protect;
         float best_ms, default_ms;
         uint32_t sample, L, runs;
     };
@@ -198,6 +199,8 @@ struct roar_index {
     int last_mode = ROAR_VISITED_LDS;
     int waves_per_cu = 0;
     int vis_entries = 0;
+    int tag_protect = -1;  // option: the forgetful tag table of an LDS-pool launch keeps the tags of pool members (roar_wave.h TagProtect); -1 = measured
+    int last_tag_protect = 0;
     int max_grid = 0;
     int search_kernel = 0;  // 0 auto, 1 one wave per query, 2 four waves per query, 3 two waves per query
     int pool_form = 0;      // 0 auto (register pool for L_pq <= 64), 1 always the LDS pool
@@ -597,6 +600,7 @@ struct PlanPick {
     int screen = -1;       // 0 off, 1 on
     int mode = -1;         // ROAR_VISITED_EXACT | ROAR_VISITED_LDS (under AUTO: the forgetful form)
     uint32_t entries = 0;  // tags of the on-chip table
+    int protect = -1;      // forgetful table of an LDS-pool launch: tags of pool members are never the victim (0 off, 1 on)
 };
 
 // does this index have a screening kernel for its rows (roar_search_v2.h: 128-d and 512-d rows, 200-d inner product)
@@ -876,6 +880,21 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     }
     // (the two-hop kernels always forget and read the field as a plain shift count: the flag is the search kernel's)
     if (mode == ROAR_VISITED_LDS && forget && !bipartite) p.vis_sets_log2 |= 0x40000000u;
+    // bit 29: bit 15 of a tag says "its node is in the pool" and the victim choice skips such ways (LDS pool only; every tag must stay
+    // below 2^15: base points / sets < 32 767)
+    // Whether that pays is the price of a revisit against ~60 more instructions per hop: with the screen a forgotten pool member costs
+    // an 8-bit row, an f32 row and a merge candidate (T2I-10M, L_pq = 1 000: 32.2 -> 30.2 ms, 500: 15.1 -> 13.6), without it one row
+    // (SIFT shape, L_pq = 170: 6.34 -> 6.53 ms).  Option "tag_protect", else what the calibration measured, else on (cmps closer to the
+    // reference's, and no dependence of cmps on the screen).
+    idx->last_tag_protect = 0;
+    const int want_protect = idx->tag_protect >= 0 ? idx->tag_protect : (pick && pick->protect >= 0) ? pick->protect : 1;
+    if (mode == ROAR_VISITED_LDS && forget && !bipartite && sel.form == ROAR_FORM_SEARCH && !sel.regpool && want_protect) {
+        const uint64_t sets = (uint64_t)(sets3 ? 3u : 1u) << sets_log2;
+        if (idx->n > 0 && (idx->n - 1) / sets + 1 < 32768u) {
+            p.vis_sets_log2 |= 0x20000000u;
+            idx->last_tag_protect = 1;
+        }
+    }
     idx->last_forgetful = (mode == ROAR_VISITED_LDS && forget) ? 1 : 0;
     p.counter = idx->counters;
     if (sel.prof) {
@@ -1856,17 +1875,18 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         float ms;
         uint32_t entries;
         int mode, screen;
+        int protect = -1;  // (-1: whatever the default rule gave; the last stage fixes it)
     };
     std::vector<Cand> tried;
     tried.reserve(16);
-    auto try_pick = [&](int screen, int mode, uint32_t entries) -> const Cand * {
+    auto try_pick = [&](int screen, int mode, uint32_t entries, int protect = -1) -> const Cand * {
         PlanPick pk;
-        pk.screen = screen, pk.mode = mode, pk.entries = entries;
-        Cand c{pk, -1.f, 0, 0, 0};
+        pk.screen = screen, pk.mode = mode, pk.entries = entries, pk.protect = protect;
+        Cand c{pk, -1.f, 0, 0, 0, protect};
         c.ms = time_pick(pk, &c.entries, &c.mode, &c.screen);
         if (c.ms < 0.f) return nullptr;
         for (const Cand &o : tried)  // (a table below the minimum for this many points is planned as the minimum: the same launch)
-            if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen) return nullptr;
+            if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen && o.protect == c.protect) return nullptr;
         if (log)
             fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: screen %s, %s, %u tags: %.3f ms\n", L, S, c.screen ? "on" : "off",
                     c.mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", c.entries, c.ms);
@@ -1883,7 +1903,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         if (default_ms >= 0.f) {
             PlanPick pk;
             pk.screen = su, pk.mode = mu, pk.entries = mu == ROAR_VISITED_LDS ? eu : 0;
-            tried.push_back(Cand{pk, default_ms, eu, mu, su});
+            tried.push_back(Cand{pk, default_ms, eu, mu, su, -1});
             if (log)
                 fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: default plan (screen %s, %s, %u tags): %.3f ms\n", L, S,
                         su ? "on" : "off", mu == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", eu, default_ms);
@@ -1928,8 +1948,11 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
                     try_pick(sc, ROAR_VISITED_LDS, 16384);
                 }
                 b = best_of();
-                if (!hard_error && b && b->mode == ROAR_VISITED_LDS && L >= 256 && b->entries >= 1024 && b->entries <= 4096)
-                    try_pick(sc, ROAR_VISITED_LDS, b->entries + b->entries / 2);
+                if (!hard_error && b && b->mode == ROAR_VISITED_LDS && L >= 256 && b->entries >= 1024 && b->entries <= 4096) {
+                    const uint32_t e0 = b->entries;
+                    try_pick(sc, ROAR_VISITED_LDS, e0 + e0 / 2);
+                    if (!hard_error && (e0 & (e0 - 1)) == 0) try_pick(sc, ROAR_VISITED_LDS, e0 - e0 / 4);
+                }
             }
         }
         // stage 3: HBM epoch tags instead of the table -- only worth a look (and the tag lists' memory) once the pool is long
@@ -1939,6 +1962,17 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         }
         if (!lds_possible && screen_free && !hard_error)
             for (int sc : screens) try_pick(sc, -1, 0);
+        // last stage: the winner with the other setting of "tag_protect" (only an on-chip table under a pool in LDS has one)
+        if (!hard_error && idx->tag_protect < 0 && L > 64) {
+            const Cand *b = best_of();
+            if (b && b->mode == ROAR_VISITED_LDS) {
+                PlanPick pk = b->pk;  // (planned once more, untimed, to learn which setting the winner ran with)
+                LaunchPlan pl;
+                const std::string keep = g_err;
+                if (plan_search(idx, S, k, L, &pl, false, &pk) == ROAR_OK) try_pick(pk.screen, pk.mode, pk.entries, idx->last_tag_protect ? 0 : 1);
+                else g_err = keep;
+            }
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1972,9 +2006,10 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     out->screen = screen_free ? best->screen : -1;
     out->mode = mode_free ? best->mode : -1;
     out->entries = (entries_free && best->mode == ROAR_VISITED_LDS) ? best->entries : 0;
+    out->protect = idx->tag_protect < 0 ? best->protect : -1;
     *calibrated = true;
     try {
-        roar_index::Calibration c{key, out->screen, out->mode, out->entries, best->ms, default_ms, S, L, runs};
+        roar_index::Calibration c{key, out->screen, out->mode, out->entries, out->protect, best->ms, default_ms, S, L, runs};
         idx->plan_cache.push_back(c);
     } catch (...) {
     }
@@ -1997,7 +2032,7 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
     PlanPick pick;
     const uint64_t key = plan_key(idx, nq, L);
     if (const roar_index::Calibration *c = find_calibration(idx, key)) {
-        pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries;
+        pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
         idx->last_calibrated = 1;
     } else if (qdev) {
         bool done = false;
@@ -3047,6 +3082,10 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
             if (value < 0 || (value > 0 && v != 1 && v != 2 && v != 3)) return fail(ROAR_ERR_ARG, "vis_entries must be 0, 2^k or 3 * 2^k");
         }
         idx->vis_entries = (int)value;
+    } else if (k == "tag_protect") {
+        if (value < -1 || value > 1) return fail(ROAR_ERR_ARG, "tag_protect must be -1 (measured), 0 or 1");
+        if (idx->tag_protect != (int)value) idx->plan_cache.clear();  // (table sizes were measured with the other setting)
+        idx->tag_protect = (int)value;
     } else if (k == "search_kernel") {
         if (value < 0 || value > 3) return fail(ROAR_ERR_ARG, "search_kernel must be 0 (auto), 1, 2 or 3");
         if (idx->search_kernel != (int)value) idx->plan_cache.clear();  // (another kernel form: measured choices no longer apply)
@@ -3109,6 +3148,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_register_pool") *value = idx->last_sel.regpool;
     else if (k == "last_hub_bitmap") *value = idx->last_sel.hub;
     else if (k == "last_screen") *value = idx->last_screen;
+    else if (k == "last_tag_protect") *value = idx->last_tag_protect;
     else if (k == "last_plan_calibrated") *value = idx->last_calibrated;
     else if (k == "last_knn_bf16") *value = idx->last_knn_bf16;
     else if (k == "last_knn_rerank_rows") *value = idx->last_knn_rerank_rows;

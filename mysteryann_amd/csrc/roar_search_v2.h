@@ -50,7 +50,8 @@ namespace {
 //     ever stored to HBM (a one-word mark costs as much as 2-3.5 lines of a row gather, scripts/probe_cost.hip).
 template <int NC>
 __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
-                                             uint32_t sets_log2, bool three, bool forget, bool (&fresh)[NC]) {
+                                             uint32_t sets_log2, bool three, bool forget, bool protect, bool (&fresh)[NC]) {
+    const uint32_t tmask = protect ? 0x7FFFu : 0xFFFFu;  // (protect: bit 15 of a tag = "its node is in the pool", roar_wave.h TagProtect)
     uint32_t *w[NC];
     uint32_t tag[NC], x[NC], y[NC];
     bool pend[NC];
@@ -84,13 +85,22 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const uint32_t t0 = x[c] & 0xFFFFu, t1 = x[c] >> 16, t2 = y[c] & 0xFFFFu, t3 = y[c] >> 16;
-            const bool hit = (t0 == tag[c]) | (t1 == tag[c]) | (t2 == tag[c]) | (t3 == tag[c]);
+            const bool hit = ((t0 & tmask) == tag[c]) | ((t1 & tmask) == tag[c]) | ((t2 & tmask) == tag[c]) | ((t3 & tmask) == tag[c]);
             const bool full = (t0 != 0) & (t1 != 0) & (t2 != 0) & (t3 != 0);
             low[c] = (t0 == 0) | (t1 == 0);
             oldw[c] = low[c] ? x[c] : y[c];
             cas[c] = pend[c] & !hit & !full;
             const bool over = pend[c] & !hit & full;  // the set is full and does not hold this id
-            if (over & forget) reinterpret_cast<uint16_t *>(w[c])[tag[c] & 3u] = (uint16_t)tag[c];
+            if (over & forget) {
+                uint32_t way = tag[c] & 3u;
+                if (protect) {  // the first way from there on whose node is not in the pool (all four are: that one after all)
+                    const uint32_t pm = (t0 >> 15) | ((t1 >> 15) << 1) | ((t2 >> 15) << 2) | ((t3 >> 15) << 3);
+                    const uint32_t rot = ((pm | (pm << 4)) >> way) & 15u;
+                    const uint32_t fr = ~rot & 15u;
+                    way = (way + (fr ? (uint32_t)__builtin_ctz(fr) : 0u)) & 3u;
+                }
+                reinterpret_cast<uint16_t *>(w[c])[way] = (uint16_t)tag[c];
+            }
             fresh[c] |= over & forget;
             spillm |= (over & !forget) ? (1u << c) : 0u;
             pend[c] = cas[c];  // visited before, victim written, or handed to the spill list: done here
@@ -624,9 +634,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     const uint32_t *const ADJ = HUB ? p.adj_hub : p.adj;
     const uint32_t AS = HUB ? p.hub_stride : p.adj_stride;
     const uint32_t L = p.L;
-    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets; bit 30: forgetful form
+    const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets; bit 30: forgetful form; bit 29: see `protect`
     const bool sets3 = (p.vis_sets_log2 >> 31) != 0;
     const bool forget = ((p.vis_sets_log2 >> 30) & 1u) != 0;
+    const bool protect = !RP && forget && ((p.vis_sets_log2 >> 29) & 1u) != 0;  // bit 29: tags carry a "node is in the pool" bit
     // (exact LDS form: the workgroup's spill list -- u16 epoch tags in HBM -- has its epoch in LDS, ctrl[6])
     const uint32_t sets_mask = (1u << sets_log2) - 1u;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -906,7 +917,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
                             }
                         } else {
-                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, forget, fresh);
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, forget, protect, fresh);
                         }
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
@@ -1012,7 +1023,11 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 for (uint32_t b = 0; b < ns; b += 64) {
                     const uint32_t cnt = (ns - b < 64u) ? ns - b : 64u;
                     if constexpr (RP) merge_regpool(pk, psize, ck + b, cnt, L, pool, lane);
-                    else merge_candidates(pool, ck + b, cnt, L, psize, cur, lane);
+                    else {
+                        TagProtect tp;
+                        if (MODE == VIS_LDS && protect) tp.vis = vis, tp.sets_mask = sets_mask, tp.sets_log2 = sets_log2, tp.three = sets3;
+                        merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp);
+                    }
                 }
                 if (PROF) t_merge += (long long)__builtin_readcyclecounter() - s0;
             }

@@ -199,6 +199,35 @@ __device__ __forceinline__ void score_candidates(const float *__restrict__ base,
     }
 }
 
+// "Never forget a node that is in the pool" (forgetful on-chip tag table, LDS pool): bit 15 of a u16 tag says its node is a pool member,
+// and the filter's victim choice skips such ways.  A revisited pool member always passes the 8-bit screen (its key is under the pool's
+// threshold), so forgetting one costs an 8-bit row AND an f32 row and a merge candidate that the duplicate test throws away; a
+// forgotten node outside the pool costs its 8-bit row.  The merge sets the bit for what it inserts and clears it for what falls off
+// the pool's end.  Needs every tag below 2^15 (the launch plan checks: base points / sets < 32 767); `vis` == nullptr: off.
+struct TagProtect {
+    uint16_t *vis = nullptr;
+    uint32_t sets_mask = 0, sets_log2 = 0;
+    bool three = false;
+};
+__device__ __forceinline__ void tag_protect(const TagProtect &tp, uint32_t id, bool on) {
+    uint32_t set = id & tp.sets_mask, hi = id >> tp.sets_log2;
+    if (tp.three) {
+        const uint32_t q3 = __umulhi(hi, 0xAAAAAAABu) >> 1;
+        set |= (hi - 3u * q3) << tp.sets_log2;
+        hi = q3;
+    }
+    const uint32_t tag = hi + 1u;
+    uint32_t *w = reinterpret_cast<uint32_t *>(tp.vis + 4 * set);
+    const uint2 ww = *reinterpret_cast<const uint2 *>(w);
+    const bool h0 = (ww.x & 0x7FFFu) == tag, h1 = ((ww.x >> 16) & 0x7FFFu) == tag, h2 = (ww.y & 0x7FFFu) == tag,
+               h3 = ((ww.y >> 16) & 0x7FFFu) == tag;
+    if (!(h0 | h1 | h2 | h3)) return;  // (its tag went to another neighbour of the same hop: it stays forgotten)
+    uint32_t *word = w + ((h0 | h1) ? 0 : 1);
+    const uint32_t bit = (h0 | h2) ? 0x8000u : 0x80000000u;
+    if (on) atomicOr(word, bit);
+    else atomicAnd(word, ~bit);
+}
+
 // NeighborPriorityQueue::insert (neighbor.h:150-183) for a batch of m <= 64 candidates at once.
 // Sequential inserts keep the top-L of everything seen; so does this merge, entry for entry.
 // Duplicate (distance, id) pairs are dropped exactly as the binary-search probe does (:161-162).
@@ -210,7 +239,7 @@ __device__ __forceinline__ void score_candidates(const float *__restrict__ base,
 // entries between two survivors' landing points all move by the same amount, so a 64-entry chunk is a read, an add and a write
 // (the first form recomputed every entry's shift from ballots over the survivors: ~75 instructions per chunk).
 __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m_, uint32_t L_, uint32_t &psize,
-                                                 uint32_t &cur, int lane) {
+                                                 uint32_t &cur, int lane, const TagProtect tp = TagProtect()) {
     const u64 FLAG = 1ull;
     // Everything that steers a loop or a branch here is the same in every lane; said so explicitly (readfirstlane), it lives in scalar
     // registers and the loops are scalar loops -- left to the compiler's divergence analysis, pool sizes that passed through LDS or
@@ -297,6 +326,9 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
                 const bool a = kidx < top;
                 const u64 e = pool[a ? kidx : lo_c];
                 if (a & (kidx + sh < L)) pool[kidx + sh] = e;
+                if (tp.vis) {
+                    if (a & !(kidx + sh < L)) tag_protect(tp, (uint32_t)e >> 1, false);  // fell off the pool's end
+                }
                 top = lo_c;
             }
         }
@@ -304,7 +336,10 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
     }
     const uint32_t pmin = hi;  // the rank-0 survivor's lower bound
     wave_sync();
-    if (valid && lo + r < L) pool[lo + r] = key;
+    if (valid && lo + r < L) {
+        pool[lo + r] = key;
+        if (tp.vis) tag_protect(tp, (uint32_t)key >> 1, true);
+    }
     psize = (P + s < L) ? P + s : L;
     const uint32_t c = uni(cur);
     cur = c < pmin ? c : pmin;  // neighbor.h:180-182

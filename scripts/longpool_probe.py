@@ -12,15 +12,17 @@ ap.add_argument("--L", type=int, nargs="+", default=[200, 500, 1000, 2000])
 ap.add_argument("--nq", type=int, default=10000)
 ap.add_argument("--tables", type=int, nargs="+", default=[2048, 4096, 8192], help="forgetful on-chip table sizes (tags; 3 * 2^k allowed)")
 ap.add_argument("--no-exact", action="store_true")
+ap.add_argument("--protect", type=int, nargs="+", default=[1], help="option tag_protect values to run the forgetful forms with")
 args = ap.parse_args()
 idx, base, queries = t2i_index(10_000_000, 10000, "reference", 0, args.graph_cache)
 q = queries[:args.nq].contiguous()
 blk = torch.zeros((args.nq, 4), dtype=torch.int32, device="cuda")
 idx.set_option("calibrate", 0); idx.set_option("screen", 2)
 for L in args.L:
-    forms = [(f"forgetful {t}", 3, t) for t in args.tables] + ([] if args.no_exact else [("exact table 4096", 1, 4096), ("HBM tags", 0, 0)])
-    for label, vm, ve in forms:
-        idx.set_option("visited_mode", vm); idx.set_option("vis_entries", ve)
+    forms = [(f"forgetful {t}" + ("" if pr else " unprotected"), 3, t, pr) for t in args.tables for pr in args.protect] + \
+            ([] if args.no_exact else [("exact table 4096", 1, 4096, 1), ("HBM tags", 0, 0, 1)])
+    for label, vm, ve, pr in forms:
+        idx.set_option("visited_mode", vm); idx.set_option("vis_entries", ve); idx.set_option("tag_protect", pr)
         idx.SetTrafficCounters(blk)
         o = idx.SearchRoarGraphBatchDevice(q, 10, L); torch.cuda.synchronize()
         idx.SetTrafficCounters(None)
@@ -29,5 +31,5 @@ for L in args.L:
         for _ in range(2):
             idx.SearchRoarGraphBatchDevice(q, 10, L); torch.cuda.synchronize()
             best = min(best, idx.info("last_kernel_ns") / 1e6)
-        print(f"L_pq {L:5d} {label:18s}: {best:8.2f} ms  cmps {o['cmps'].double().mean().item():9.1f}  rows 8-bit {t[0].item():9.1f}  rows f32 {t[1].item():8.1f}  "
+        print(f"L_pq {L:5d} {label:28s}: {best:8.2f} ms  cmps {o['cmps'].double().mean().item():9.1f}  rows 8-bit {t[0].item():9.1f}  rows f32 {t[1].item():8.1f}  "
               f"adjacency words {t[2].item():9.0f}  hops {o['hops'].double().mean().item():7.1f}  LDS {idx.info('last_lds_bytes')} B, grid {idx.info('last_grid')}", flush=True)

@@ -345,6 +345,54 @@ def test_full_sets_spill_or_forget_without_moving_results(built_lib):
     assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["cmps"], o["cmps"])
 
 
+def test_pool_members_keep_their_tags_without_moving_results(built_lib):
+    """Option "tag_protect" (forgetful on-chip table under a pool in LDS): bit 15 of a tag says "its node is in the pool", the victim
+    choice skips such ways, the merge sets the bit for what it inserts and clears it for what falls off the pool's end (the replacement
+    policy the last verdict asked for; visited_list_pool.h:8-29 is what the table stands in for).  Tables far smaller than the pool,
+    2^k and 3 * 2^k sets, with and without the 8-bit screen, both metrics: ids / distances / hops are the reference's with either
+    setting, cmps never below the reference's, and the protected table does not score more rows than the unprotected one.  (What it
+    saves is measured where it matters -- f32 rows of revisited pool members behind the 8-bit screen on the benchmark graph:
+    profiles/r04_long_pools_lds.txt; on random graphs a revisit is as likely to be of any node as of a pool member.)"""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    # (the third set is small against its pools: a search keeps meeting its own pool again -- where the policy has something to do)
+    for metric, d, n, maxdeg in ((1, 200, 30000, 40), (0, 128, 20000, 48), (0, 128, 2500, 48)):
+        base, q, off, nbrs = _random_case(n, d, 48, metric, seed=23 + d, maxdeg=maxdeg)
+        idx = mi.IndexBipartite(d, n, metric, None)
+        idx.SetBaseData(base)
+        idx.SetProjectionGraph(1, off, nbrs)
+        idx.set_option("calibrate", 0), idx.set_option("hub_mode", 1), idx.set_option("visited_mode", 3)
+        gains = []
+        for L in (70, 300):
+            o = oracle.search_batch(base, off, nbrs, 1, q, K, L, metric)
+            for screen in (1, 2):
+                if screen == 2 and not (metric == 1 and d == 200) and d != 128:
+                    continue
+                idx.set_option("screen", screen)
+                tot = {0: 0, 1: 0}
+                for ve in ((64, 192, 256) if L == 70 else (256, 768, 1024)):
+                    idx.set_option("vis_entries", ve)
+                    for prot in (0, 1):
+                        idx.set_option("tag_protect", prot)
+                        r = idx.SearchRoarGraphBatch(q, K, L)
+                        assert idx.info("last_visited_forgetful") == 1 and idx.info("last_tag_protect") == prot
+                        assert idx.info("last_vis_entries") == ve and idx.info("last_register_pool") == 0
+                        for key in ("ids", "dists", "hops"):
+                            assert np.array_equal(r[key], o[key]), (metric, L, screen, ve, prot, key)
+                        assert (r["cmps"] >= o["cmps"]).all()
+                        tot[prot] += int(r["cmps"].sum())
+                # (which tags go is a heuristic either way: a table much smaller than the pool has nothing but protected ways to evict)
+                assert tot[1] <= 1.002 * tot[0], (metric, L, screen, tot)
+                gains.append(1.0 - tot[1] / tot[0])
+        assert min(gains) > -0.002, gains
+        # a pool in registers has no such table
+        idx.set_option("tag_protect", 1), idx.set_option("vis_entries", 256)
+        idx.SearchRoarGraphBatch(q, K, 40)
+        assert idx.info("last_register_pool") == 1 and idx.info("last_tag_protect") == 0
+        idx.close()
+
+
 def test_spill_list_epoch_wrap(built_lib):
     """More than 65 535 queries through one resident workgroup: the u16 epoch of its spill list wraps and the list is cleared
     (VisitedList::reset, visited_list_pool.h:20-26).  Tiny table, tiny pool, one workgroup."""
@@ -1332,8 +1380,9 @@ def test_screening_pass_never_changes_a_result(mode, shape, built_lib):
     idx.SetBaseData(base)
     idx.SetProjectionGraph(5, off, nbrs)
     idx.set_option("visited_mode", mode)
-    if mode == 3:  # (the plan picks table size and hub bitmap by what a hop gathers: the same form with and without the screen)
+    if mode == 3:  # (the plan picks table size, tag policy and hub bitmap by what a hop gathers: the same form with and without the screen)
         idx.set_option("vis_entries", 4096)
+        idx.set_option("tag_protect", 1)
         idx.set_option("hub_mode", 1)
     for L in (10, 50, 64, 65, 300):
         o = oracle.search_batch(base, off, nbrs, 5, q, K, L, 1 if ip else 0)

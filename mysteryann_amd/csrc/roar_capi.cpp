@@ -888,13 +888,17 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // reference's, and no dependence of cmps on the screen).
     idx->last_tag_protect = 0;
     const int want_protect = idx->tag_protect >= 0 ? idx->tag_protect : (pick && pick->protect >= 0) ? pick->protect : 1;
-    if (mode == ROAR_VISITED_LDS && forget && !bipartite && sel.form == ROAR_FORM_SEARCH && !sel.regpool && want_protect) {
+    sel.protect = 0;
+    if (mode == ROAR_VISITED_LDS && forget && !bipartite && sel.form == ROAR_FORM_SEARCH && !sel.regpool && sel.waves == 1 && !sel.hub &&
+        want_protect) {
         const uint64_t sets = (uint64_t)(sets3 ? 3u : 1u) << sets_log2;
         if (idx->n > 0 && (idx->n - 1) / sets + 1 < 32768u) {
             p.vis_sets_log2 |= 0x20000000u;
+            sel.protect = 1;
             idx->last_tag_protect = 1;
         }
     }
+    idx->last_sel = sel;
     idx->last_forgetful = (mode == ROAR_VISITED_LDS && forget) ? 1 : 0;
     p.counter = idx->counters;
     if (sel.prof) {
@@ -2084,6 +2088,11 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
             return fail(ROAR_ERR_ARG, "internal: this kernel form cannot wait for the packing thread");
         p.ready = ready_dev;
         plan.sel.gated = 1;
+        if (plan.sel.protect) {  // (the gated form has no instantiation that keeps pool members' tags: the plain forgetful table)
+            plan.sel.protect = 0;
+            p.vis_sets_log2 &= ~0x20000000u;
+            idx->last_tag_protect = 0;
+        }
     }
     // Launches of one index on different streams may overlap (each has its own launch cell) -- except where they would
     // share per-workgroup state in HBM: the EXACT-mode tag lists / the spill lists are indexed by workgroup, so such a

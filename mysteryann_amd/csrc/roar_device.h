@@ -87,6 +87,7 @@ struct RoarKernelSel {
     int hub;           // SEARCH: hub-bitmap form (LDS pool only)
     int gated;         // SEARCH, one wave per query, no hub / prof: queries become readable while the launch runs (RoarSearchParams::ready)
     int stats;         // SEARCH, one wave per query, no hub / prof / gate: the instantiation that fills RoarSearchParams::out_traffic
+    int protect;       // SEARCH, LDS visited mode, one wave per query, pool in LDS, no hub / gate: forgetful table that keeps pool members' tags
 };
 
 struct RoarDistParams {

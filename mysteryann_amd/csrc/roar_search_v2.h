@@ -51,7 +51,7 @@ namespace {
 template <int NC>
 __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
                                              uint32_t sets_log2, bool three, bool forget, bool protect, bool (&fresh)[NC]) {
-    const uint32_t tmask = protect ? 0x7FFFu : 0xFFFFu;  // (protect: bit 15 of a tag = "its node is in the pool", roar_wave.h TagProtect)
+    const uint32_t tmask2 = protect ? 0x7FFF7FFFu : 0xFFFFFFFFu;  // (protect: bit 15 of a tag = "its node is in the pool", roar_wave.h TagProtect)
     uint32_t *w[NC];
     uint32_t tag[NC], x[NC], y[NC];
     bool pend[NC];
@@ -84,8 +84,9 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
         uint32_t oldw[NC], got[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const uint32_t t0 = x[c] & 0xFFFFu, t1 = x[c] >> 16, t2 = y[c] & 0xFFFFu, t3 = y[c] >> 16;
-            const bool hit = ((t0 & tmask) == tag[c]) | ((t1 & tmask) == tag[c]) | ((t2 & tmask) == tag[c]) | ((t3 & tmask) == tag[c]);
+            const uint32_t xm = x[c] & tmask2, ym = y[c] & tmask2;
+            const uint32_t t0 = xm & 0xFFFFu, t1 = xm >> 16, t2 = ym & 0xFFFFu, t3 = ym >> 16;  // (a protected tag is not 0 either)
+            const bool hit = (t0 == tag[c]) | (t1 == tag[c]) | (t2 == tag[c]) | (t3 == tag[c]);
             const bool full = (t0 != 0) & (t1 != 0) & (t2 != 0) & (t3 != 0);
             low[c] = (t0 == 0) | (t1 == 0);
             oldw[c] = low[c] ? x[c] : y[c];
@@ -94,7 +95,7 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
             if (over & forget) {
                 uint32_t way = tag[c] & 3u;
                 if (protect) {  // the first way from there on whose node is not in the pool (all four are: that one after all)
-                    const uint32_t pm = (t0 >> 15) | ((t1 >> 15) << 1) | ((t2 >> 15) << 2) | ((t3 >> 15) << 3);
+                    const uint32_t pm = ((x[c] >> 15) & 1u) | ((x[c] >> 31) << 1) | (((y[c] >> 15) & 1u) << 2) | ((y[c] >> 31) << 3);
                     const uint32_t rot = ((pm | (pm << 4)) >> way) & 15u;
                     const uint32_t fr = ~rot & 15u;
                     way = (way + (fr ? (uint32_t)__builtin_ctz(fr) : 0u)) & 3u;
@@ -609,7 +610,9 @@ __device__ __forceinline__ void lds_barrier() {
 // hop, plus one LDS add of lane 0 where something is fetched.  Its own instantiation because the kernels of the benchmark
 // shapes sit exactly at their register budget (the counting costs the one-wave 200-d kernel 12 bytes of scratch inside the hop);
 // what a query fetches does not depend on timing, so the counts are those of the plain kernel on the same launch plan.
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false, bool STATS = false>
+// PROT: the instantiation whose forgetful tag table keeps the tags of pool members (roar_wave.h TagProtect; LDS pool, one wave per query).
+// Its own instantiation for the same reason: the policy's code costs a launch that does not use it 2 % (SIFT shape, L_pq = 170).
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false, bool STATS = false, bool PROT = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
@@ -637,7 +640,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets; bit 30: forgetful form; bit 29: see `protect`
     const bool sets3 = (p.vis_sets_log2 >> 31) != 0;
     const bool forget = ((p.vis_sets_log2 >> 30) & 1u) != 0;
-    const bool protect = !RP && forget && ((p.vis_sets_log2 >> 29) & 1u) != 0;  // bit 29: tags carry a "node is in the pool" bit
+    const bool protect = PROT && !RP && forget && ((p.vis_sets_log2 >> 29) & 1u) != 0;  // bit 29: tags carry a "node is in the pool" bit
     // (exact LDS form: the workgroup's spill list -- u16 epoch tags in HBM -- has its epoch in LDS, ctrl[6])
     const uint32_t sets_mask = (1u << sets_log2) - 1u;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -1128,10 +1131,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #ifndef ROAR_WPE_512
 #define ROAR_WPE_512 2
 #endif
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false, bool STATS = false>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false, bool STATS = false, bool PROT = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(NCH > 16 ? ROAR_WPE_512 : 3, NCH > 16 ? ROAR_WPE_512 : 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED, STATS>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED, STATS, PROT>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -1151,6 +1154,21 @@ const void *pick_form(const RoarKernelSel &s) {
                       : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
         else
             return nullptr;
+    }
+    if constexpr (MODE == VIS_LDS) {
+        if (s.protect) {  // the forgetful table keeps the tags of pool members: one wave per query, pool in LDS, no hub bitmap / gate
+            if (rp || s.waves != 1 || s.hub || s.gated) return nullptr;
+            if (s.stats) return s.prof ? nullptr : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, true, true>;
+            if (s.prof) {
+                if constexpr ((IP && NCH == 12) || (!IP && NCH == 8))
+                    return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true, false, false, false, true>;
+                else
+                    return nullptr;
+            }
+            return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, false, true>;
+        }
+    } else {
+        if (s.protect) return nullptr;
     }
     if (s.stats) {  // one wave per query, counting what each query fetches (RoarSearchParams::out_traffic)
         if (s.prof || s.waves != 1 || s.gated || (s.hub && rp)) return nullptr;

@@ -354,6 +354,7 @@ def test_pool_members_keep_their_tags_without_moving_results(built_lib):
     saves is measured where it matters -- f32 rows of revisited pool members behind the 8-bit screen on the benchmark graph:
     profiles/r04_long_pools_lds.txt; on random graphs a revisit is as likely to be of any node as of a pool member.)"""
     import oracle
+    import torch
     from mysteryann_amd import index as mi
 
     # (the third set is small against its pools: a search keeps meeting its own pool again -- where the policy has something to do)
@@ -363,6 +364,7 @@ def test_pool_members_keep_their_tags_without_moving_results(built_lib):
         idx.SetBaseData(base)
         idx.SetProjectionGraph(1, off, nbrs)
         idx.set_option("calibrate", 0), idx.set_option("hub_mode", 1), idx.set_option("visited_mode", 3)
+        qd = torch.from_numpy(q).cuda()
         gains = []
         for L in (70, 300):
             o = oracle.search_batch(base, off, nbrs, 1, q, K, L, metric)
@@ -375,7 +377,8 @@ def test_pool_members_keep_their_tags_without_moving_results(built_lib):
                     idx.set_option("vis_entries", ve)
                     for prot in (0, 1):
                         idx.set_option("tag_protect", prot)
-                        r = idx.SearchRoarGraphBatch(q, K, L)
+                        # (queries on the device: a pageable host block takes the gated kernel form, which has no such instantiation)
+                        r = {k_: v.cpu().numpy() for k_, v in idx.SearchRoarGraphBatchDevice(qd, K, L).items()}
                         assert idx.info("last_visited_forgetful") == 1 and idx.info("last_tag_protect") == prot
                         assert idx.info("last_vis_entries") == ve and idx.info("last_register_pool") == 0
                         for key in ("ids", "dists", "hops"):
@@ -388,8 +391,12 @@ def test_pool_members_keep_their_tags_without_moving_results(built_lib):
         assert min(gains) > -0.002, gains
         # a pool in registers has no such table
         idx.set_option("tag_protect", 1), idx.set_option("vis_entries", 256)
-        idx.SearchRoarGraphBatch(q, K, 40)
+        idx.SearchRoarGraphBatchDevice(qd, K, 40)
         assert idx.info("last_register_pool") == 1 and idx.info("last_tag_protect") == 0
+        r = idx.SearchRoarGraphBatch(q, K, 300)  # a pageable host block: the gated form, plain forgetful table, same results
+        assert idx.info("last_tag_protect") == 0
+        for key in ("ids", "dists", "hops"):
+            assert np.array_equal(r[key], o[key]), key
         idx.close()
 
 

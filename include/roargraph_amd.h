@@ -347,6 +347,11 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    (that call synchronises its stream; results never depend on the plan; ROAR_LOG_CALIBRATION=1 in the environment
  *                    prints every decision); 0: fixed defaults (screen on for rows of 768 bytes and more, the on-chip table with
  *                    4 096 / 8 192 tags up to L_pq = 1 536, HBM tags beyond); 2: forget what was measured so far
+ *   "tag_protect"    forgetful on-chip tag table under a candidate pool in LDS (L_pq > 64, one wave per query, device or pinned queries):
+ *                    1 = a tag whose node is in the pool is never the victim of an insertion (bit 15 of the tag, kept by the queue's
+ *                    merge; needs base points / sets < 32 767) -- a forgotten pool member is the expensive revisit: it always passes
+ *                    the 8-bit screen and costs an f32 row and a merge candidate; 0 = plain replacement; -1 (default) = measured by
+ *                    the calibration, on without one.  Results do not depend on it; cmps moves towards the reference's
  *   "knn_mode"       roar_exact_knn(_device): 0 (default) bf16 MFMA screen with a rigorous per-row bound + exact f32 re-rank in the
  *                    reference's summation order (csrc/roar_knn_bf16.hip; it hands over to form 1 when the bound cannot be claimed),
  *                    1 every score by f32 MFMA (csrc/roar_knn.hip)
@@ -360,7 +365,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
  *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
  *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "screen_row_bytes" (bytes per
- *   row of the 8-bit screening copy at this dimension), "last_visited_forgetful", "last_plan_calibrated" (1 if the most recent search ran a measured plan),
+ *   row of the 8-bit screening copy at this dimension), "last_visited_forgetful", "last_tag_protect", "last_plan_calibrated" (1 if the most recent search ran a measured plan),
  *   "calibrations" (launch kinds measured so far), "last_knn_bf16" (1 if the most recent exact kNN call ran the bf16-screened form), "last_knn_rerank_rows" (rows it scored on f32), "last_kernel_ns"
  *   (duration of the most recent search kernel, measured with HIP events on its own stream;
  *   reading it synchronises on those events). */

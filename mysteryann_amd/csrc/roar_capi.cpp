@@ -1892,8 +1892,9 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         for (const Cand &o : tried)  // (a table below the minimum for this many points is planned as the minimum: the same launch)
             if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen && o.protect == c.protect) return nullptr;
         if (log)
-            fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: screen %s, %s, %u tags: %.3f ms\n", L, S, c.screen ? "on" : "off",
-                    c.mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", c.entries, c.ms);
+            fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: screen %s, %s, %u tags%s: %.3f ms\n", L, S, c.screen ? "on" : "off",
+                    c.mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", c.entries,
+                    c.protect == 1 ? ", pool members' tags kept" : c.protect == 0 ? ", plain replacement" : "", c.ms);
         tried.push_back(c);
         return &tried.back();
     };
@@ -2018,9 +2019,10 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     } catch (...) {
     }
     if (log)
-        fprintf(stderr, "[roar calibration] L_pq=%u nq=%llu key=%llx -> screen %s, %s, %u tags: %.3f ms (default plan %.3f ms), %u launches\n", L,
+        fprintf(stderr, "[roar calibration] L_pq=%u nq=%llu key=%llx -> screen %s, %s, %u tags%s: %.3f ms (default plan %.3f ms), %u launches\n", L,
                 (unsigned long long)nq, (unsigned long long)key, best->screen ? "on" : "off",
-                best->mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", best->entries, best->ms, default_ms, runs);
+                best->mode == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", best->entries,
+                best->protect == 1 ? ", pool members' tags kept" : best->protect == 0 ? ", plain replacement" : "", best->ms, default_ms, runs);
     return ROAR_OK;
 }
 

@@ -179,6 +179,33 @@ def _random_case(n, d, nq, metric, seed, maxdeg=40):
     return base, q, off, nbrs
 
 
+def test_pool_lengths_across_the_merge_s_boundaries(built_lib):
+    """The LDS-pool merge (csrc/roar_wave.h merge_candidates) changes gear with the pool's length: binary search alone up to 128 entries,
+    64 splitters + a search inside a (length / 64)-entry segment above (segment length 3 from 129, 4 from 193, 5 from 257 ...), shifts
+    in whole 64-entry chunks, four at a time from 256 entries to move, and a masked chunk at either end.  Every L_pq around those
+    boundaries on a small graph whose searches keep meeting their own pool (duplicates), forgetful table (duplicates reach the
+    merge) and exact tags: ids, distances, hops as the oracle's; cmps as well in the exact form."""
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 1500, 24, 24
+    base, q, off, nbrs = _random_case(n, d, nq, 0, seed=77, maxdeg=60)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(7, off, nbrs)
+    idx.set_option("calibrate", 0), idx.set_option("hub_mode", 1)
+    Ls = [65, 66, 127, 128, 129, 130, 131, 191, 192, 193, 194, 255, 256, 257, 258, 319, 320, 321, 383, 384, 385, 449, 511, 512, 513,
+          640, 641, 1023, 1024, 1025, 1400]
+    for L in Ls:
+        o = oracle.search_batch(base, off, nbrs, 7, q, K, L, 0, threads=4)
+        for mode, ve in ((3, 64), (3, 1024), (0, 0)):
+            idx.set_option("visited_mode", mode), idx.set_option("vis_entries", ve)
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            for key in ("ids", "dists", "hops") + (("cmps",) if mode == 0 else ()):
+                assert np.array_equal(r[key], o[key]), (L, mode, ve, key)
+    idx.close()
+
+
 @pytest.mark.parametrize("d", [8, 24, 128, 200, 264, 512])
 @pytest.mark.parametrize("metric", [0, 1])
 def test_random_graphs_against_oracle(d, metric, built_lib):

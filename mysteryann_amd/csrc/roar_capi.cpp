@@ -671,7 +671,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // Visited form.  An option fixes it; under AUTO it is what the calibration measured on this index (the on-chip tag table,
     // forgetful, against u8 epoch tags in HBM: the table wins while the pool's nodes mostly fit it, the HBM tags beyond -- where
     // "beyond" starts depends on the graph, the row length and the screen: L_pq ~ 500 ... 1 950 on the sets measured so far,
-    // profiles/r02_hub_forms*.txt, r03_screen_forms.txt, r04_calibration.txt).  Without a measurement (option "calibrate" = 0,
+    // profiles/r02_hub_forms*.txt, r03_screen_forms.txt, r04_long_pools_lds.txt, r04_bench_L1000_stderr.txt).  Without a measurement (option "calibrate" = 0,
     // the builder's searches): the table up to L_pq = 1 536.
     // (a u16 tag needs sets >= n / 65534; beyond ~134 M points per index that table no longer fits the cap)
     const bool lds_fits = (idx->n + 65533) / 65534 <= 2048;

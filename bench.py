@@ -276,6 +276,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-share-probe", action="store_true",
                     help="N = 1: skip the emulated share of 8 (the timed loop once more over the first nq / 8 rows of every batch)")
     ap.add_argument("--no-screen", action="store_true", help="switch the 8-bit screening pass off (option screen = 1)")
+    ap.add_argument("--force-screen", action="store_true", help="8-bit screening pass on wherever there is a kernel (option screen = 2) instead of measured")
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
     ap.add_argument("--tune", action="store_true", help="time the chosen L_pq over visited-table sizes (stderr)")
     ap.add_argument("--sweep", action="store_true", help="print the whole L_pq curve (CSV columns of the reference)")
@@ -405,7 +406,7 @@ def main():
         if not cached or not args.L:
             raise SystemExit("--pmc-child needs --graph-cache (an existing file) and --L")
         idx.set_option("visited_mode", {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}[args.visited])
-        idx.set_option("screen", 1 if args.no_screen else 0)
+        idx.set_option("screen", 1 if args.no_screen else 2 if args.force_screen else 0)
         if args.vis_entries:
             idx.set_option("vis_entries", args.vis_entries)
         if args.plan:  # the plan the parent measured and timed: the same launches here, whatever this process would have measured
@@ -441,7 +442,7 @@ def main():
         f"({'torch' if args.torch_gt else 'roar_exact_knn_device'})")
 
     VIS = {"exact": 0, "lds": 1, "auto": 2, "forgetful": 3}
-    idx.set_option("screen", 1 if args.no_screen else 0)
+    idx.set_option("screen", 1 if args.no_screen else 2 if args.force_screen else 0)
     idx.set_option("visited_mode", VIS[args.visited])
     if args.vis_entries:
         idx.set_option("vis_entries", args.vis_entries)

@@ -1,6 +1,6 @@
 // What the matrix cores give a loop shaped like the exact-kNN pass kernel's: 8 waves per CU (2 per SIMD), A fragments in registers,
 // 13 v_mfma_f32_32x32x16_bf16 per 32 x 32 block.  Variants: B from registers or from LDS (ds_read_b128, three buffers), one or two
-// accumulator chains, with or without 32 verdict-like VALU instructions per block between the MFMAs.
+// accumulator chains, with or without 32 verdict-like VALU instructions per block between the MFMAs (singly, or two per v_pk_fma_f32).
 //   hipcc -O3 --offload-arch=gfx950 -o mfma_probe mfma_probe.hip && ./mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,7 +26,8 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <bool LDS, int CHAINS, bool VALU>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool LDS, int CHAINS, bool VALU, bool PK = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) probe(const uint4 *src, float *out, int iters) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -38,6 +39,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int ks = 0; ks < KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, src[(tid * KS + ks) % (64 * KQ)]);
     float thr[16], eq[16];
     for (int g = 0; g < 16; ++g) thr[g] = 1e30f + g + lane, eq[g] = 0.001f * (g + 1);
+    f32x2 eq2[8];
+    for (int g = 0; g < 8; ++g) eq2[g] = f32x2{eq[2 * g], eq[2 * g + 1]};
     f32x16 acc[2];
     for (int g = 0; g < 16; ++g) acc[0][g] = 0.f, acc[1][g] = 0.f;
     const uint32_t a0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(buf + r * KQ + h);
@@ -65,10 +68,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 } else {
                     cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], af[(ks + 1) % KS], cur, 0, 0, 0);
                 }
-                if constexpr (VALU && CHAINS == 2) {
+                if constexpr (VALU && CHAINS == 2 && !PK) {
                     static_for<0, 16>([&](auto cg) {
                         constexpr int g = decltype(cg)::value;
                         if constexpr ((g * KS) / 16 == ks) anyacc |= __ballot(-__builtin_fmaf(eq[g], xn, old[g]) <= -thr[g]);
+                    });
+                }
+                if constexpr (VALU && CHAINS == 2 && PK) {  // two verdicts per v_pk_fma_f32
+                    static_for<0, 8>([&](auto cg) {
+                        constexpr int g = decltype(cg)::value;
+                        if constexpr ((g * KS) / 8 == ks) {
+                            const f32x2 v = __builtin_elementwise_fma(eq2[g], f32x2{xn, xn}, f32x2{old[2 * g], old[2 * g + 1]});
+                            anyacc |= __ballot(-v.x <= -thr[2 * g]);
+                            anyacc |= __ballot(-v.y <= -thr[2 * g + 1]);
+                        }
                     });
                 }
             });
@@ -83,14 +96,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     out[blockIdx.x * 512 + tid] = s;
 }
 
-template <bool LDS, int CHAINS, bool VALU>
+template <bool LDS, int CHAINS, bool VALU, bool PK = false>
 void run(const char *name, const uint4 *src, float *out, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const size_t lds = 64 * (2 * KS + 1) * 16;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<LDS, CHAINS, VALU>), dim3(256), dim3(512), lds, 0, src, out, iters);
+        hipLaunchKernelGGL((probe<LDS, CHAINS, VALU, PK>), dim3(256), dim3(512), lds, 0, src, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -113,5 +126,6 @@ int main() {
     run<true, 1, false>("B from LDS, one chain", src, out, iters);
     run<true, 2, true>("B from LDS, two chains, verdicts under the MFMAs", src, out, iters);
     run<true, 1, true>("B from LDS, one chain, verdicts after the MFMAs", src, out, iters);
+    run<true, 2, true, true>("B from LDS, two chains, verdicts in pairs (v_pk_fma_f32)", src, out, iters);
     return 0;
 }

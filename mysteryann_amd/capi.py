@@ -54,7 +54,7 @@ class RoarError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h")) or f in ("roar_capi.cpp", "roar_sharded.cpp")]
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h")) or (f.endswith(".cpp") and not f.startswith("harness_"))]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "roargraph_amd.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

@@ -121,14 +121,21 @@ def implemented_bytes(rows_code, rows_f32, adj_words, queries, dim_padded, scree
             + (4.0 * dim_padded + 8.0 * k) * float(queries))
 
 
-def share_of_8_block(nq, steps, wall_share, wall_share_serial, depth, cap, value_this_run):
+def share_of_8_block(nq, steps, wall_share, wall_share_serial, depth, cap, value_this_run, wall_stream=None, stream_info=None):
     """config.emulated_share_of_8: what the strong-scaling run at N = 8 asks of each rank -- nq / 8 queries per step -- timed on THIS GPU
-    over the same K steps (wall seconds with `depth` launches in flight / one at a time).  The eight ranks run side by side, so the
-    projected whole-job rate is nq x K / that wall time; its ratio to this run's own value is the projected speed-up."""
-    return {"queries_per_launch": nq // 8, "launches_in_flight": depth, "workgroups_per_launch_cap": cap,
-            "ms_per_step": wall_share * 1e3 / steps, "ms_per_step_one_launch_at_a_time": wall_share_serial * 1e3 / steps,
-            "projected_value_8_gpus": nq * steps / wall_share,
-            "projected_speedup_over_this_run": (nq * steps / wall_share) / value_this_run,
+    over the same K steps (wall seconds through one batch stream / with `depth` launches in flight / one at a time).  The eight ranks
+    run side by side, so the projected whole-job rate is nq x K / that wall time; its ratio to this run's own value is the projected
+    speed-up.  The regime is the better of {batch stream, launches in flight}, named in `regime`, as for `value` itself."""
+    use_stream = wall_stream is not None and wall_stream < wall_share
+    best = wall_stream if use_stream else wall_share
+    return {"queries_per_step": nq // 8, "regime": "one batch stream (roar_search_stream_*)" if use_stream else f"{depth} launches in flight",
+            "ms_per_step": best * 1e3 / steps,
+            "projected_value_8_gpus": nq * steps / best,
+            "projected_speedup_over_this_run": (nq * steps / best) / value_this_run,
+            "ms_per_step_batch_stream": None if wall_stream is None else wall_stream * 1e3 / steps,
+            "ms_per_step_launches_in_flight": wall_share * 1e3 / steps, "launches_in_flight": depth, "workgroups_per_launch_cap": cap,
+            "ms_per_step_one_launch_at_a_time": wall_share_serial * 1e3 / steps,
+            "batch_stream": stream_info,
             "note": "a projection from ONE GPU: the first nq / 8 rows of every batch on this GPU stand for one of eight ranks"}
 
 
@@ -275,6 +282,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-share-probe", action="store_true",
                     help="N = 1: skip the emulated share of 8 (the timed loop once more over the first nq / 8 rows of every batch)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the batch-stream regime (roar_search_stream_*): launches in flight only")
     ap.add_argument("--no-screen", action="store_true", help="switch the 8-bit screening pass off (option screen = 1)")
     ap.add_argument("--force-screen", action="store_true", help="8-bit screening pass on wherever there is a kernel (option screen = 2) instead of measured")
     ap.add_argument("--vis-entries", type=int, default=0, help="LDS visited-table entries (0 = auto)")
@@ -550,14 +558,64 @@ def main():
         run(chosen, 0, outs[0], st_)
     torch.cuda.synchronize()
 
-    def timed(order, in_flight=1):
+    def step_buffers(rows):
+        """one set of result arrays per step of a timed loop whose steps overlap (steps s and s + B search the same batch: they must
+        not share their result arrays)"""
+        return [dict(ids=torch.empty((rows, args.k), dtype=torch.int32, device=dev), dists=torch.empty((rows, args.k), dtype=torch.float32, device=dev),
+                     cmps=torch.empty(rows, dtype=torch.int32, device=dev), hops=torch.empty(rows, dtype=torch.int32, device=dev),
+                     scanned=torch.empty(rows, dtype=torch.int32, device=dev), short=torch.zeros(1, dtype=torch.int32, device=dev))
+                for _ in range(max(args.steps, args.warmup, 1))]
+
+    def timed_stream(order, bufs):
+        """The same K steps through ONE batch stream (roar_search_stream_*): every step's batch is submitted and waited for inside the
+        timed region; workgroups are not bound to a step -- they take queries from whatever has been submitted and cross step
+        boundaries, so a step's last queries run beside the next steps' first ones without a launch per step.  The stream is opened
+        (buffers, plan) outside the region, as the HIP streams of the other loop are made outside it; its workgroups are started by
+        the first submit inside.  -> (wall s max over ranks, GPU span ms from the device clock: first query taken .. last batch
+        complete, info)"""
+        st_ = idx.OpenSearchStream(args.k, chosen)
+        try:
+            tk = [st_.submit(batches[order(s_)], bufs[s_])[0] for s_ in range(args.warmup)]
+            for t__ in tk:
+                st_.wait(t__)
+            t_end = time.time() + 2.0
+            while st_.info("workgroups_alive") and time.time() < t_end:  # (the timed region starts from an idle stream)
+                time.sleep(0.0005)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            launches0 = st_.info("launches")
+            t_ = time.perf_counter()
+            tk = [st_.submit(batches[order(s_)], bufs[s_])[0] for s_ in range(args.steps)]
+            for t__ in tk:
+                st_.wait(t__)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            wall_ = time.perf_counter() - t_
+            if use_dist:
+                t = torch.tensor([wall_], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall_ = t.item()
+            tt = [st_.times(t__) for t__ in tk]
+            span_ms = (max(b_ for _, b_ in tt) - min(a_ for a_, _ in tt)) * 1e-6
+            info_ = {"kernel_launches_in_the_timed_region": st_.info("launches") - launches0, "resident_workgroups": st_.info("resident_capacity"),
+                     "times_wait_had_to_start_workgroups": st_.info("heals"), "screen": bool(st_.info("screen")),
+                     "vis_entries": st_.info("vis_entries"), "lds_bytes": st_.info("lds_bytes")}
+        finally:
+            st_.close()
+        return wall_, span_ms, info_
+
+    def timed(order, in_flight=1, bufs=None):
         """`steps` launches, batch of step s = order(s); barrier + synchronize on both sides; -> (wall s max over ranks, gpu ms).
         in_flight > 1: step s is launched on stream s mod in_flight, so that a step's last queries (a launch ends with its
         slowest query: 72 hops against 61 on average) run beside the next step's first ones; every step still searches its
-        own whole batch into its own result buffers inside the timed region."""
+        own whole batch into its own result buffers (`bufs`: one set per step) inside the timed region."""
         streams = [main_stream] if in_flight <= 1 else side[:in_flight]
         for s_ in range(args.warmup):
-            run(chosen, order(s_), outs[order(s_)], streams[s_ % len(streams)])
+            run(chosen, order(s_), bufs[s_] if bufs else outs[order(s_)], streams[s_ % len(streams)])
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -569,7 +627,7 @@ def main():
             if st_ is not main_stream:
                 st_.wait_event(e0)
         for s_ in range(args.steps):
-            run(chosen, order(s_), outs[order(s_)], streams[s_ % len(streams)])
+            run(chosen, order(s_), bufs[s_] if bufs else outs[order(s_)], streams[s_ % len(streams)])
         for st_ in streams:
             if st_ is not main_stream:
                 main_stream.wait_stream(st_)
@@ -615,10 +673,27 @@ def main():
         # 1.522 with two uncapped launches; 5 000 0.750 / 0.817; 2 500 0.389 / 0.466; 1 250 0.212 / 0.307 ms)
         pipe_grid = args.launch_grid if args.launch_grid >= 0 else (1024 if mine >= 8000 else 640)
         idx.set_option("max_grid", pipe_grid)
-        wall, gpu_pipe = timed(lambda s_: s_ % B, depth)
+        sbufs = step_buffers(mine)
+        wall, gpu_pipe = timed(lambda s_: s_ % B, depth, sbufs)
         idx.set_option("max_grid", 0)
     else:
         wall, gpu_pipe = wall_serial, gpu_ms
+        sbufs = step_buffers(mine)
+    wall_launches, gpu_launches = wall, gpu_pipe
+    # the same K steps through ONE batch stream (round 5): workgroups outlive a step.  `value` is the better of the two regimes and
+    # config.value_regime names it; both are in the line.
+    stream_info = None
+    wall_stream = gpu_stream = None
+    if not args.no_stream:
+        wall_stream, gpu_stream, stream_info = timed_stream(lambda s_: s_ % B, sbufs)
+        stream_info["results_equal_per_launch_results"] = all(
+            bool((sbufs[s_]["ids"] == outs[s_ % B]["ids"]).all().item() and (sbufs[s_]["dists"] == outs[s_ % B]["dists"]).all().item()
+                 and (sbufs[s_]["hops"] == outs[s_ % B]["hops"]).all().item()) for s_ in range(args.steps))
+        log(f"[rank {rank}] batch stream: {wall_stream * 1e3 / args.steps:.4f} ms per step (launches in flight: {wall_launches * 1e3 / args.steps:.4f}), "
+            f"{stream_info}")
+    use_stream = wall_stream is not None and wall_stream < wall_launches
+    if use_stream:
+        wall, gpu_pipe = wall_stream, gpu_stream
     ms_per_step = wall * 1e3 / args.steps
     qps = total_q * args.steps / wall
     # N > 1, strong scaling: the same K steps once more with every rank on WHOLE batches of its own (rank r starts the rotation at
@@ -647,11 +722,18 @@ def main():
         torch.cuda.synchronize()
         share_grid = args.launch_grid if args.launch_grid >= 0 else 640
         idx.set_option("max_grid", share_grid if depth > 1 else 0)
-        wall_s8, gpu_s8 = timed(lambda s_: s_ % B, depth)
+        shbufs = step_buffers(sh)
+        wall_s8, gpu_s8 = timed(lambda s_: s_ % B, depth, shbufs)
         idx.set_option("max_grid", 0)
         wall_s8_1, _ = timed(lambda s_: s_ % B)
+        wall_s8_stream = s8_info = None
+        if not args.no_stream:
+            wall_s8_stream, _, s8_info = timed_stream(lambda s_: s_ % B, shbufs)
+            s8_info["results_equal_per_launch_results"] = all(
+                bool((shbufs[s_]["ids"] == outs[s_ % B]["ids"]).all().item() and (shbufs[s_]["dists"] == outs[s_ % B]["dists"]).all().item())
+                for s_ in range(args.steps))
         batches, outs = keep_b, keep_o
-        share8 = share_of_8_block(args.nq, args.steps, wall_s8, wall_s8_1, depth, share_grid if depth > 1 else 0, qps)
+        share8 = share_of_8_block(args.nq, args.steps, wall_s8, wall_s8_1, depth, share_grid if depth > 1 else 0, qps, wall_s8_stream, s8_info)
 
     ref_bytes_per_launch = float(np.mean([alg_bytes[s_ % B] for s_ in range(args.steps)]))
     bytes_per_launch = float(np.mean([impl_bytes[s_ % B] for s_ in range(args.steps)]))
@@ -661,8 +743,10 @@ def main():
     eff_ms = gpu_pipe / args.steps
     achieved = bytes_per_launch / (eff_ms * 1e-3) / 1e9
     achieved_serial = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    regime = (f"{depth} launches in flight on {depth} streams, at most {pipe_grid} workgroups each: kernel_ms = GPU span of the {args.steps} "
-              f"timed launches / {args.steps} (HIP events on the launch streams)") if depth > 1 else \
+    regime = ("one batch stream (roar_search_stream_*), every step's batch submitted and waited for inside the timed region, workgroups cross "
+              f"step boundaries: kernel_ms = device-clock span first query taken .. last batch complete / {args.steps}") if use_stream else \
+        (f"{depth} launches in flight on {depth} streams, at most {pipe_grid} workgroups each: kernel_ms = GPU span of the {args.steps} "
+         f"timed launches / {args.steps} (HIP events on the launch streams)") if depth > 1 else \
         "one launch at a time: kernel_ms = HIP events around the timed launches / steps"
 
     result = {
@@ -690,6 +774,9 @@ def main():
                    "rccl_ranks_seen": ranks_seen,
                    "query_batches_rotated": B, "ms_per_step_same_batch_replayed": wall_replay * 1e3 / args.steps,
                    "launches_in_flight": depth, "workgroups_per_launch_cap_in_flight": pipe_grid,
+                   "value_batch_stream": None if wall_stream is None else total_q * args.steps / wall_stream,
+                   "value_launches_in_flight": total_q * args.steps / wall_launches,
+                   "batch_stream": stream_info,
                    "value_with_a_whole_batch_per_rank_and_step_weak_scaling": weak_value, "ms_per_step_one_launch_at_a_time": wall_serial * 1e3 / args.steps,
                    "value_one_launch_at_a_time": total_q * args.steps / wall_serial,
                    "emulated_share_of_8": share8,

@@ -186,6 +186,43 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
                              uint32_t *hops_dev, uint32_t *scanned_dev, uint32_t *short_count_dev,
                              void *hip_stream);
 
+/* ---- a stream of batches (device buffers) -----------------------------------------------------------------------------------------
+ * Replaces the harness loop tests/test_search_roargraph.cpp:202-212 when batches follow one another -- a serving loop, or one GPU's
+ * share of every batch at N = 8 (1 250 of 10 000 queries, BASELINE configs[3]): a launch per batch ends with its slowest query
+ * while most of the chip idles.  Here a batch is not a launch.  submit() PUBLISHES the batch (a 64-byte record in pinned host memory)
+ * and returns a ticket; workgroups of the batch-stream form of the search kernel take queries from the published batches in batch
+ * order, cross batch boundaries, and leave only when nothing published is left (an open but idle stream holds no part of the chip,
+ * and nothing on the GPU ever waits for the host); submit() starts workgroups when fewer are alive than the chip holds and queries are
+ * waiting.  wait() returns when every query of the ticket's batch has its results in device memory -- readable from then on by a
+ * hipMemcpy or by any kernel launched afterwards.  Results per batch are bit-identical to roar_search_batch_device (same search code;
+ * cmps as with visited_mode LDS_FORGETFUL: >= the reference's).
+ *   open    k, L_pq for every batch of the stream.  visited_mode must be AUTO or LDS_FORGETFUL (workgroups of several launches live
+ *           side by side: nothing may be indexed by workgroup in HBM); the launch plan (screen, table size) is what the index's
+ *           calibration measured for the largest batches at this L_pq -- measured on the first batch if it has not been yet.
+ *   submit  as roar_search_batch_device without a stream argument: the batch must be COMPLETE in device memory when submit is called
+ *           (synchronise whatever wrote it) and must stay valid and unchanged until its ticket has been waited for; the result
+ *           arrays likewise.  At most 256 batches may be incomplete at a time (submit blocks on the oldest beyond that).  nq = 0:
+ *           ticket 0, nothing to wait for.  Thread-safe; several host threads may submit to and wait on one stream.
+ *   wait    blocks (polling pinned memory) until the batch is complete; *short_count (may be NULL) = queries of the batch that ended
+ *           with fewer than k results (tail ids 0xFFFFFFFF).  Tickets may be waited for in any order, more than once, or never.
+ *           A batch that does not complete within 60 s fails the stream (ROAR_ERR_DEVICE; every later call fails, close() returns
+ *           the error and leaks the stream's buffers rather than free memory a kernel may still read).
+ *   times   device wall clock (ns since an arbitrary origin) at which the batch's first query was taken and its last query finished.
+ *   close   waits for every submitted batch and for the stream's launches to end, then frees the stream.
+ * While a stream is open the index's base rows and graph must not be replaced (those calls fail with ROAR_ERR_ARG), and other
+ * searches on the same device share the chip with the stream's workgroups.
+ * info keys: "launches" (kernel launches so far), "workgroups_launched", "workgroups_alive", "resident_capacity", "heals" (times
+ * wait() found a batch pending and no workgroup alive), "epochs", "batches_submitted", "batches_completed", "ring", "lds_bytes",
+ * "screen", "vis_entries", "tag_protect", "register_pool", "wall_clock_khz". */
+typedef struct roar_stream roar_stream;
+int roar_search_stream_open(roar_index *idx, uint32_t k, uint32_t L_pq, roar_stream **out);
+int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t *ids_dev,
+                              float *dists_dev, uint32_t *cmps_dev, uint32_t *hops_dev, uint32_t *scanned_dev, uint64_t *ticket);
+int roar_search_stream_wait(roar_stream *s, uint64_t ticket, uint32_t *short_count);
+int roar_search_stream_times(roar_stream *s, uint64_t ticket, uint64_t *first_ns, uint64_t *done_ns);
+int roar_search_stream_info(roar_stream *s, const char *key, int64_t *value);
+int roar_search_stream_close(roar_stream *s);
+
 /* ---- replicated index, one query block split over g devices (BASELINE configs[3]) ---------
  * The reference has ONE query set and one timed loop over it (tests/test_search_roargraph.cpp:202-209); queries share
  * only read-only state (src/index_bipartite.cpp:2311-2420 has no cross-query dependence), so the block shards by

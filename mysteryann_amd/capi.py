@@ -30,7 +30,8 @@ SYMBOLS = [
     "roar_rebase_ids_device", "roar_sharded_create", "roar_sharded_destroy", "roar_sharded_shard",
     "roar_sharded_set_id_base", "roar_search_batch_sharded", "roar_sharded_info", "roar_host_register",
     "roar_host_unregister", "roar_debug_fail_device_alloc_at", "roar_debug_screen_keeps",
-    "roar_set_traffic_counters_device",
+    "roar_set_traffic_counters_device", "roar_search_stream_open", "roar_search_stream_submit", "roar_search_stream_wait",
+    "roar_search_stream_times", "roar_search_stream_info", "roar_search_stream_close",
 ]
 
 
@@ -131,6 +132,12 @@ def lib():
     l.roar_debug_fail_device_alloc_at.argtypes = [C.c_int64]
     l.roar_debug_screen_keeps.argtypes = [vp, fp, C.c_uint64, C.c_uint32, u32p, fp, C.c_uint32, C.POINTER(C.c_uint8)]
     l.roar_set_traffic_counters_device.argtypes = [vp, vp, C.c_uint64]
+    l.roar_search_stream_open.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    l.roar_search_stream_submit.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp, u64p]
+    l.roar_search_stream_wait.argtypes = [vp, C.c_uint64, u32p]
+    l.roar_search_stream_times.argtypes = [vp, C.c_uint64, u64p, u64p]
+    l.roar_search_stream_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    l.roar_search_stream_close.argtypes = [vp]
     l.roar_host_register.argtypes = [vp, C.c_uint64]
     l.roar_host_unregister.argtypes = [vp]
     l.roar_rebase_ids_device.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]

@@ -8,6 +8,7 @@ extern "C" {
 
 int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !bp) return fail(ROAR_ERR_ARG, "bad arguments");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "build needs base vectors in HBM");
     const uint32_t M = bp->M, base_cap = bp->base_cap, max_degree = bp->max_degree, L_build = bp->L_build;
@@ -228,6 +229,7 @@ int roar_build_graph(roar_index *idx, const roar_build_params *bp) {
 int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                                 uint32_t M_pjbp, uint32_t L_pjpq) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !lists_dev || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
     if (M_pjbp == 0 || M_pjbp > 128) return fail(ROAR_ERR_ARG, "M_pjbp must be in 1..128");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
@@ -402,6 +404,7 @@ int roar_build_roargraph_device(roar_index *idx, const uint32_t *lists_dev, uint
 int roar_build_roargraph(roar_index *idx, const uint32_t *learn_knn, uint64_t n_learn, uint32_t K, uint32_t M_sq,
                          uint32_t M_pjbp, uint32_t L_pjpq) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !learn_knn || n_learn == 0 || K < 2) return fail(ROAR_ERR_ARG, "learn base knn file error");
     if (!idx->base || idx->n < 2) return fail(ROAR_ERR_ARG, "BuildRoarGraph needs the base vectors first");
     const uint32_t C = std::min<uint32_t>(std::min<uint32_t>(M_sq ? M_sq : K, K), 255u);

@@ -42,6 +42,12 @@ int use_device(roar_index *idx) {
     return ROAR_OK;
 }
 
+int refuse_while_streaming(const roar_index *idx) {
+    if (idx && idx->streams_open.load() > 0)
+        return fail(ROAR_ERR_ARG, "a search stream is open on this index (roar_search_stream_open): close it before replacing base rows or graph");
+    return ROAR_OK;
+}
+
 void free_graph(roar_index *idx) {
     idx->plan_cache.clear();  // (measured on the graph that goes away)
     if (idx->adj) (void)hipFree(idx->adj);
@@ -396,6 +402,10 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
 }
 
 void roar_destroy(roar_index *idx) {
+    if (idx && idx->streams_open.load() > 0) {  // (workgroups may still be reading the index: leak it rather than free it under them)
+        (void)fail(ROAR_ERR_ARG, "roar_destroy: a search stream is still open on this index; the index was NOT freed");
+        return;
+    }
     DeviceRestore keep_device_;
     if (!idx) return;
     (void)hipSetDevice(idx->device);
@@ -419,6 +429,7 @@ void roar_destroy(roar_index *idx) {
 
 int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_stride_floats) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !rows || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
     if (row_stride_floats < idx->dim) return fail(ROAR_ERR_ARG, "row stride smaller than the dimension");
     int e = use_device(idx);
@@ -442,6 +453,7 @@ int roar_set_base(roar_index *idx, const float *rows, uint64_t n, uint32_t row_s
 
 int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uint32_t row_stride_floats) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !rows_dev || n == 0) return fail(ROAR_ERR_ARG, "bad base arguments");
     if (row_stride_floats < idx->dim_pad || (row_stride_floats & 3))
         return fail(ROAR_ERR_ARG, "device rows need a stride >= %u floats that is a multiple of 4", idx->dim_pad);
@@ -460,6 +472,7 @@ int roar_set_base_device(roar_index *idx, const float *rows_dev, uint64_t n, uin
 
 int roar_load_base_fbin(roar_index *idx, const char *path) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ROAR_ERR_IO, "open file error");  // util.h:109-112
@@ -512,6 +525,7 @@ int roar_load_base_fbin(roar_index *idx, const char *path) {
 
 int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t *offsets, const uint32_t *nbrs) {
     DeviceRestore keep_device_;
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !offsets || (n && !nbrs && offsets[n] != 0)) return fail(ROAR_ERR_ARG, "bad graph arguments");
     if (n == 0 || n >= (1ull << 31)) return fail(ROAR_ERR_ARG, "graph must have between 1 and 2^31 nodes");
     if (ep >= n) return fail(ROAR_ERR_FORMAT, "entry point %u outside the graph (%llu nodes)", ep, (unsigned long long)n);
@@ -566,6 +580,7 @@ int roar_set_graph_csr(roar_index *idx, uint32_t ep, uint64_t n, const uint64_t 
 }
 
 int roar_load_graph_file(roar_index *idx, const char *path) {
+    if (int busy_ = refuse_while_streaming(idx)) return busy_;
     if (!idx || !path) return fail(ROAR_ERR_ARG, "bad arguments");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ROAR_ERR_IO, "cannot open file");

@@ -3,6 +3,39 @@
 #pragma once
 #include <stdint.h>
 
+// ---- batch-stream form (roar_search_stream_*, roar_stream.cpp; kernel: SRC == 2 in roar_search_v2.h) -----------------------------
+// Workgroups do not belong to a launch's batch: they take queries from a ring of SUBMITTED batches, cross batch boundaries, and
+// leave when nothing published is left.  The host publishes a batch by writing its slot and then `tail`; the kernel reports a
+// finished batch in the slot's RoarStreamDone.  All three live in pinned (coherent) host memory; the per-batch counters
+// (RoarStreamCell) live in device memory, one per batch NUMBER -- never recycled while any workgroup is alive, so a late
+// workgroup can touch a counter of a long finished batch without harm.
+struct RoarStreamSlot {   // 64 bytes, ring position = batch number % ring; written by the host (seqlock: seq1 = 0 first, the fields, seq1 last)
+    uint64_t queries;     // device pointers of the batch (out_cmps / out_hops / out_scanned may be 0)
+    uint64_t out_ids, out_dists, out_cmps, out_hops, out_scanned;
+    uint32_t nq;
+    uint32_t qstride;     // floats
+    uint32_t pad;
+    uint32_t seq1;        // batch number + 1 (0 while the slot is being rewritten)
+};
+struct RoarStreamDone {   // 32 bytes, one per ring position; written by the kernel
+    uint64_t t_first;     // device wall clock (100 MHz) when the batch's first query was taken ...
+    uint64_t t_done;      // ... and when its last query had its results in device memory
+    uint32_t nshort;      // queries that returned fewer than k results
+    uint32_t seq1_done;   // batch number + 1 once every query of the batch has its results in device memory (written last)
+    uint32_t seq1_claimed;  // batch number + 1 once the batch's last query has been handed out (the host then starts no workgroups for it)
+    uint32_t pad;
+};
+struct RoarStreamCtl {    // 64 bytes
+    uint32_t tail;        // batches published so far (host writes, workgroups read)
+    uint32_t exited;      // workgroups that have left, all launches of the stream together (workgroups add, host reads)
+    uint32_t pad[14];
+};
+struct RoarStreamCell {   // device memory, one per batch number
+    unsigned long long done_short;  // low word: queries finished; high word: of those, short ones (one 64-bit add per query)
+    uint32_t next;                  // next query of the batch to hand out (grows past nq: harmless)
+    uint32_t pad;
+};
+
 struct RoarSearchParams {
     // base vectors: f32 rows, `ld` floats apart, scored over `dim` floats (dim % 8 == 0, zero padded)
     const float *base;
@@ -73,6 +106,16 @@ struct RoarSearchParams {
     // u32[nq][4] = {rows scored on the 8-bit screening copy, rows scored on the f32 rows (entry point included), adjacency
     // words fetched (whole 64-word chunks; speculative fetches that were dropped included), 0}
     uint32_t *out_traffic;
+    // batch-stream form (sel.stream): device addresses of the pinned control blocks, the per-batch counters, ring size (a power of
+    // two), the first batch number a workgroup of THIS launch looks at (every earlier batch is complete), and the LDS block (128 bytes)
+    // that holds a workgroup's copy of the slot it works on
+    const RoarStreamCtl *s_ctl;
+    const RoarStreamSlot *s_slots;
+    RoarStreamDone *s_done;
+    RoarStreamCell *s_cells;
+    uint32_t s_ring;
+    uint32_t s_start;
+    uint32_t off_stream;
 };
 
 // Which kernel a launch runs.
@@ -88,6 +131,7 @@ struct RoarKernelSel {
     int gated;         // SEARCH, one wave per query, no hub / prof: queries become readable while the launch runs (RoarSearchParams::ready)
     int stats;         // SEARCH, one wave per query, no hub / prof / gate: the instantiation that fills RoarSearchParams::out_traffic
     int protect;       // SEARCH, LDS visited mode, one wave per query, pool in LDS, no hub / gate: forgetful table that keeps pool members' tags
+    int stream;        // SEARCH, LDS visited mode (forgetful), one wave per query, no hub / prof / gate / stats: queries come from a ring of submitted batches
 };
 
 struct RoarDistParams {

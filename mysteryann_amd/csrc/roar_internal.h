@@ -257,6 +257,7 @@ struct roar_index {
     // last launch
     int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
     std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel form, LDS bytes) -> resident workgroups per CU
+    std::atomic<int> streams_open{0};  // roar_search_stream_open .. _close: base rows and graph must stay as they are meanwhile
 };
 
 namespace roar_impl {
@@ -293,6 +294,7 @@ struct PlanPick {
     int mode = -1;         // ROAR_VISITED_EXACT | ROAR_VISITED_LDS (under AUTO: the forgetful form)
     uint32_t entries = 0;  // tags of the on-chip table
     int protect = -1;      // forgetful table of an LDS-pool launch: tags of pool members are never the victim (0 off, 1 on)
+    int stream = 0;        // 1: plan the batch-stream form of the kernel (roar_stream.cpp): one wave per query, forgetful on-chip table
 };
 
 // does this index have a screening kernel for its rows (roar_search_v2.h: 128-d and 512-d rows, 200-d inner product)
@@ -302,6 +304,7 @@ inline bool has_screen_kernel(const roar_index *idx) {
 
 // roar_capi.cpp
 int use_device(roar_index *idx);
+int refuse_while_streaming(const roar_index *idx);  // base rows / graph are about to change: not while a search stream is open
 void free_graph(roar_index *idx);
 void free_bipartite(roar_index *idx);
 void free_base(roar_index *idx);
@@ -325,6 +328,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
 // has not been seen yet), defaults otherwise.  *need_queries (may be null): set when a calibration is due but qdev is null.
 int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
                  bool *need_queries);
+
+// The plan of a stream's workgroups (roar_stream.cpp): the batch-stream form of the kernel, with what the calibration measured for
+// the largest batches of this L_pq (measuring it now on `qdev` if need be); plan->grid = the workgroups the chip holds at once.
+int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan);
 
 // roar_launch.cpp
 int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st);

@@ -61,7 +61,8 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // degree 32 gathers 16 KB per hop and behaves like a sparse one (SIFT-1M shape, L_pq = 170: hub form 9.59 ms, plain 8.0 ms).
     const bool dense = !p.screen && idx->gn && (double)idx->nedges / (double)idx->gn * (double)idx->dim_pad * 4.0 >= 24.0 * 800.0;
     bool use_hub = false;
-    if (!bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
+    const bool stream = pick && pick->stream && !bipartite && !idx->building;  // batch-stream form (roar_stream.cpp): one wave per query, forgetful table
+    if (!stream && !bipartite && !idx->building && L > 64 && idx->hub_mode != 1 && (idx->hub_mode == 2 || (dense && L >= 100))) {
         int e = ensure_hub_rows(idx);
         if (e) return e;
         use_hub = idx->hub_state == 1;
@@ -77,7 +78,13 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // so much that LDS mode re-scores 1.5-2.7x the nodes, T2I-10M bipartite sweep: EXACT 21.5 / 47.0 / 94.0 ms
     // vs LDS 34.0 / 79.7 / 185 ms at L_pq = 10 / 100 / 500 -> AUTO is EXACT there)
     int mode = idx->visited_mode;
-    if (mode == ROAR_VISITED_AUTO) {
+    if (stream) {
+        // workgroups of several launches live side by side: nothing may be indexed by workgroup number in HBM (tag lists, spill lists)
+        if (!lds_fits) return fail(ROAR_ERR_ARG, "the batch-stream form runs the on-chip tag table, which %llu base points do not fit", (unsigned long long)idx->n);
+        if (mode == ROAR_VISITED_EXACT || mode == ROAR_VISITED_LDS)
+            return fail(ROAR_ERR_ARG, "the batch-stream form runs the forgetful on-chip tag table: option visited_mode must be AUTO or LDS_FORGETFUL");
+        mode = ROAR_VISITED_LDS_FORGETFUL;
+    } else if (mode == ROAR_VISITED_AUTO) {
         if (bipartite || !lds_fits) mode = ROAR_VISITED_EXACT;
         else if (pick && pick->mode >= 0 && !idx->building) mode = pick->mode == ROAR_VISITED_EXACT ? ROAR_VISITED_EXACT : ROAR_VISITED_LDS;
         else mode = L < 1536u ? ROAR_VISITED_LDS : ROAR_VISITED_EXACT;
@@ -155,6 +162,10 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         p.bp_off = idx->bp_off;
         p.bp_nbrs = idx->bp_nbrs;
     }
+    if (stream) {  // the workgroup's copy of the slot it works on + its place in the stream (roar_search_v2.h stream_take)
+        p.off_stream = off;
+        off += 128;
+    }
     p.lds_bytes = off;
     if (p.lds_bytes > 160 * 1024) return fail(ROAR_ERR_ARG, "L_pq = %u needs %u bytes of LDS per query (max 163840)", L, off);
     // kernel form: W waves per query while the whole batch is resident that way (latency forms), one wave per
@@ -168,12 +179,14 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     sel.regpool = (L <= 64 && idx->pool_form == 0) ? 1 : 0;
     sel.prof = idx->profile ? 1 : 0;
     sel.hub = use_hub ? 1 : 0;
+    sel.stream = stream ? 1 : 0;
+    if (stream && sel.prof) return fail(ROAR_ERR_ARG, "profile_phases: the batch-stream form has no instrumented kernel");
     if (sel.prof && !(idx->ip && idx->dim_pad == 200) && !(!idx->ip && idx->dim_pad == 128))
         return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product and the 128-d L2 shapes only");
     int occ = 0;
     auto occupancy = [&](int *out) -> int {
         // (asked once per kernel form and LDS size: a stream of launches of one shape must not pay a runtime query each)
-        const uint64_t key = ((uint64_t)p.lds_bytes << 32) | ((uint64_t)(sel.form & 7) << 28) | ((uint64_t)(sel.waves & 7) << 24) |
+        const uint64_t key = ((uint64_t)p.lds_bytes << 32) | ((uint64_t)(sel.stream & 1) << 31) | ((uint64_t)(sel.form & 7) << 28) | ((uint64_t)(sel.waves & 7) << 24) |
                              ((uint64_t)(sel.visited_mode & 3) << 20) | ((uint64_t)(sel.regpool & 1) << 19) | ((uint64_t)(sel.prof & 1) << 18) |
                              ((uint64_t)(sel.hub & 1) << 17) | ((uint64_t)(sel.metric_ip & 1) << 16) | (uint64_t)(idx->dim_pad & 0xFFFF);
         for (const auto &e : idx->occ_cache)
@@ -199,7 +212,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         int e = occupancy(&occ);
         if (e) return e;
         picked = true;
-    } else if (idx->search_kernel != 1 && !idx->building) {
+    } else if (idx->search_kernel != 1 && !idx->building && !stream) {
         // search_kernel: 0 auto, 1 one wave per query, 2 four waves, 3 two waves.  Auto: four waves for batches of at most
         // one query per CU on a dense graph (a hop gathers ~100 rows: one pass instead of three -- 256 queries at L_pq = 30
         // on the T2I-10M bootstrap graph 0.305 vs 0.329 ms); one wave otherwise.  On a sparse graph a hop gathers ~50 rows
@@ -607,5 +620,32 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
         return ROAR_OK;
     }
     return plan_search(idx, nq, k, L, plan, false, &pick);
+}
+
+int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan) {
+    PlanPick pick;
+    idx->last_calibrated = 0;
+    const bool sane = idx->base && idx->adj && idx->gn == idx->n && L != 0 && k != 0 && k <= L;  // (else: plan_search words the error)
+    if (sane && calibratable(idx)) {
+        // A stream's workgroups share the chip with each other whatever the size of the batches: the regime of the largest batches,
+        // as for a launch under a grid cap (plan_key) -- its calibration is taken, or made now on this batch's queries.
+        const int cap_keep = idx->max_grid;
+        idx->max_grid = 0x7FFFFFFF;
+        const uint64_t key = plan_key(idx, nq, L);
+        int e = ROAR_OK;
+        if (const roar_index::Calibration *c = find_calibration(idx, key)) {
+            pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
+            idx->last_calibrated = 1;
+        } else if (qdev) {
+            bool done = false;
+            e = calibrate_plan(idx, qdev, nq, qstride, k, L, st, &pick, &done);
+            idx->last_calibrated = done ? 1 : 0;
+        }
+        idx->max_grid = cap_keep;
+        if (e) return e;
+    }
+    if (pick.mode == ROAR_VISITED_EXACT) pick.mode = -1, pick.entries = 0;  // (HBM tags won the calibration: the stream runs the table anyway)
+    pick.stream = 1;
+    return plan_search(idx, 1ull << 30, k, L, plan, false, &pick);
 }
 }  // namespace roar_impl

@@ -597,6 +597,124 @@ __device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane,
     }
 }
 
+// ---- batch-stream form (SRC == 2; host side: roar_stream.cpp) --------------------------------------------------------------------
+// A workgroup does not belong to a launch's batch: it takes queries from the ring of SUBMITTED batches (RoarStreamSlot, pinned host
+// memory), in batch order, crosses batch boundaries, and leaves when nothing published is left -- so a batch's last queries run beside
+// the next batches' first ones without any launch boundary (the loop being split: tests/test_search_roargraph.cpp:202-212).
+// Its block in LDS (32 words at p.off_stream): 0-15 copy of the slot it works on, 16 `want` = the batch number it takes queries from,
+// 17 batches published as last seen, 18 batch number + 1 of the copy (0: none).
+// Memory the host or another launch may rewrite between batches (slots, query rows) is read with system-scope loads -- a workgroup
+// that lives across batches never passes the L2 invalidate of a kernel start -- and results are stored write-through (system scope),
+// so that "every query of the batch has finished" (one 64-bit add per query on the batch's counter cell) means "its results are in
+// device memory" for whoever the host lets read them next.
+__device__ __forceinline__ uint32_t sys_load32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 lds_ptr(const volatile uint32_t *sl, int w) { return ((u64)sl[w + 1] << 32) | (u64)sl[w]; }
+
+// What the stream's bookkeeping needs from the kernel arguments is read from the kernel-argument segment where it is used, once or twice
+// per QUERY, instead of living in scalar registers through every hop (the kernels of the benchmark shapes sit at their register budget).
+struct StreamArgs {
+    RoarStreamCtl *ctl;
+    const RoarStreamSlot *slots;
+    RoarStreamDone *done;
+    RoarStreamCell *cells;
+    uint32_t ring_mask;
+    volatile uint32_t *sl;
+};
+__device__ __forceinline__ StreamArgs stream_args() {
+    StreamArgs a;
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __align__(16) unsigned char smem_[];
+    const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    a.ctl = const_cast<RoarStreamCtl *>(*const_cast<const RoarStreamCtl *const volatile *>(&ka->s_ctl));
+    a.slots = *const_cast<const RoarStreamSlot *const volatile *>(&ka->s_slots);
+    a.done = *const_cast<RoarStreamDone *const volatile *>(&ka->s_done);
+    a.cells = *const_cast<RoarStreamCell *const volatile *>(&ka->s_cells);
+    a.ring_mask = *const_cast<const uint32_t volatile *>(&ka->s_ring) - 1u;
+    a.sl = reinterpret_cast<volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_stream));
+#else
+    a = StreamArgs{};  // (host pass of the compiler: never executed)
+#endif
+    return a;
+}
+
+// -> true: q = a query of batch sl[16], whose slot is in sl[0..15]; false: nothing published is left and the workgroup has signed
+// off (RoarStreamCtl::exited).  Wave-uniform.
+__device__ __forceinline__ bool stream_take(int lane, uint32_t &q) {
+    const StreamArgs a = stream_args();
+    volatile uint32_t *const sl = a.sl;
+    for (;;) {
+        const uint32_t want = sl[16];
+        if (want >= sl[17]) {  // past what this workgroup has seen published: look again
+            uint32_t t = 0;
+            if (lane == 0) t = __hip_atomic_load(&a.ctl->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            t = uni(t);
+            if (want >= t) {
+                // Nothing left.  Sign off, then look ONCE more: the host publishes a batch and THEN reads `exited` to decide whether
+                // workgroups must be launched for it -- one of the two sees the other's write.  (roar_search_stream_wait also starts
+                // workgroups when it finds none alive: a lost race costs time, never a batch.)
+                if (lane == 0) {
+                    (void)__hip_atomic_fetch_add(&a.ctl->exited, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                    t = __hip_atomic_load(&a.ctl->tail, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                t = uni(t);
+                if (want >= t) return false;
+                if (lane == 0) (void)__hip_atomic_fetch_sub(&a.ctl->exited, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (lane == 0) sl[17] = t;
+            wave_sync();
+        }
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&a.cells[want].next, 1u);
+        idx = uni(idx);
+        if (sl[18] != want + 1u) {  // the copy is another batch's: fetch the slot (64 bytes over PCIe), seqlock-checked
+            const RoarStreamSlot *slot = a.slots + (want & a.ring_mask);
+            uint32_t w = 0;
+            if (lane < 16) w = sys_load32(reinterpret_cast<const uint32_t *>(slot) + lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the second look at seq1 must be sampled after the fields)
+            uint32_t again = 0;
+            if (lane == 0) again = sys_load32(&slot->seq1);
+            const bool ok = lane_u32(w, 15) == want + 1u && uni(again) == want + 1u;
+            if (lane < 16) sl[lane] = w;
+            if (lane == 0) sl[18] = ok ? want + 1u : 0u;
+            wave_sync();
+            if (!ok) {  // the slot already holds a later batch: batch `want` was complete long ago
+                if (lane == 0) sl[16] = want + 1u;
+                wave_sync();
+                continue;
+            }
+        }
+        if (idx >= sl[12]) {  // the batch has no query left to hand out: on to the next one
+            if (lane == 0) sl[16] = want + 1u;
+            wave_sync();
+            continue;
+        }
+        if (idx == 0 && lane == 0)
+            __hip_atomic_store(&a.done[want & a.ring_mask].t_first, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (idx + 1u == sl[12] && lane == 0) sys_store32(&a.done[want & a.ring_mask].seq1_claimed, want + 1u);
+        q = idx;
+        return true;
+    }
+}
+
+// The query is done and its results are stored (write-through): count it; the workgroup that finishes a batch's last query reports
+// the batch to the host.
+__device__ __forceinline__ void stream_finish(int lane, bool was_short) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every result store of this query has been acknowledged by memory
+    if (lane == 0) {
+        const StreamArgs a = stream_args();
+        const uint32_t want = a.sl[16];
+        const u64 add = 1ull + (was_short ? (1ull << 32) : 0ull);
+        const u64 now = atomicAdd(&a.cells[want].done_short, add) + add;
+        if ((uint32_t)now == a.sl[12]) {
+            RoarStreamDone *d = a.done + (want & a.ring_mask);
+            __hip_atomic_store(&d->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sys_store32(&d->nshort, (uint32_t)(now >> 32));
+            __hip_atomic_store(&d->seq1_done, want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue, which would
 // make wave 0 sit out the round trip of its speculative adjacency fetch before the other waves may start scoring;
 // everything the waves of a query hand each other (candidate ids, keys, control words) lives in LDS.
@@ -612,8 +730,12 @@ __device__ __forceinline__ void lds_barrier() {
 // what a query fetches does not depend on timing, so the counts are those of the plain kernel on the same launch plan.
 // PROT: the instantiation whose forgetful tag table keeps the tags of pool members (roar_wave.h TagProtect; LDS pool, one wave per query).
 // Its own instantiation for the same reason: the policy's code costs a launch that does not use it 2 % (SIFT shape, L_pq = 170).
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, bool GATED = false, bool STATS = false, bool PROT = false>
+// SRC: where the queries come from -- 0 the launch's own batch (p.queries, p.nq); 1 the same while a host thread is still packing the
+// rows (waits on p.ready; pageable host query blocks); 2 the batch-stream form: a ring of submitted batches (stream_take).
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, int SRC = 0, bool STATS = false, bool PROT = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
+    constexpr bool GATED = SRC == 1, STREAM = SRC == 2;
+    static_assert(!STREAM || (W == 1 && !PROF && !HUB && !STATS && MODE == VIS_LDS), "batch-stream form: one wave per query, on-chip tag table");
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
     constexpr int SD = (NCH == 8 && !TAIL) ? 128 : (NCH == 32 && !TAIL) ? 512 : (IP && NCH == 12 && TAIL) ? 200 : 0;
@@ -659,9 +781,19 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         block_sync();
     }
 
+    if constexpr (STREAM) {
+        if (lane == 0) {
+            volatile uint32_t *const sl = stream_args().sl;
+            sl[16] = p.s_start, sl[17] = 0u, sl[18] = 0u;
+        }
+        wave_sync();
+    }
+
     for (;;) {
         uint32_t q = 0;
-        if constexpr (W == 1) {
+        if constexpr (STREAM) {
+            if (!stream_take(lane, q)) return;  // (signed off in RoarStreamCtl::exited; the launch cell is not used)
+        } else if constexpr (W == 1) {
             if (lane == 0) q = atomicAdd(p.counter, 1u);
             q = uni(q);
         } else {
@@ -669,7 +801,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             lds_barrier();
             q = ctrl[0];
         }
-        if (q >= p.nq) break;
+        if (!STREAM && q >= p.nq) break;
         if (GATED && q >= ready_seen) {
             // the host is still packing the query block behind this launch: wait until row q is there (the counter only
             // grows, so a workgroup looks at it again only when it runs past what it has seen)
@@ -685,9 +817,15 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         if (PROF) tq0 = (long long)__builtin_readcyclecounter();
 
         // query -> LDS (tests/test_search_roargraph.cpp:205 passes aligned_query_data + i * q_dim)
-        const float *qp = p.queries + (u64)q * p.qstride;
-        for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
-            *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        if constexpr (STREAM) {  // (rows another launch or a copy may have rewritten since this workgroup last saw them: system-scope loads)
+            volatile uint32_t *const sl = stream_args().sl;
+            const uint32_t *qp = reinterpret_cast<const uint32_t *>(lds_ptr(sl, 0)) + (u64)q * sl[13];
+            for (uint32_t i = threadIdx.x; i < p.dim; i += 64) reinterpret_cast<uint32_t *>(lq)[i] = sys_load32(qp + i);
+        } else {
+            const float *qp = p.queries + (u64)q * p.qstride;
+            for (uint32_t i = threadIdx.x * 4; i < p.dim; i += 256 * W)
+                *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
+        }
         if (MODE == VIS_LDS) {  // fresh visited table
             const uint32_t n16 = ((sets3 ? 12u : 4u) << sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
             for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
@@ -1045,11 +1183,18 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #else
             const RoarSearchParams *ka = &p;  // (host pass of the compiler: never executed)
 #endif
-            uint32_t *const o_ids = *const_cast<uint32_t *const volatile *>(&ka->out_ids);
-            float *const o_dists = *const_cast<float *const volatile *>(&ka->out_dists);
-            uint32_t *const o_cmps = *const_cast<uint32_t *const volatile *>(&ka->out_cmps);
-            uint32_t *const o_hops = *const_cast<uint32_t *const volatile *>(&ka->out_hops);
-            uint32_t *const o_scanned = *const_cast<uint32_t *const volatile *>(&ka->out_scanned);
+            // (batch-stream form: the batch's own arrays, from the workgroup's copy of its slot; stores are write-through)
+            [[maybe_unused]] volatile uint32_t *sl = nullptr;
+            if constexpr (STREAM) sl = stream_args().sl;
+            uint32_t *const o_ids = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 2)) : *const_cast<uint32_t *const volatile *>(&ka->out_ids);
+            float *const o_dists = STREAM ? reinterpret_cast<float *>(lds_ptr(sl, 4)) : *const_cast<float *const volatile *>(&ka->out_dists);
+            uint32_t *const o_cmps = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 6)) : *const_cast<uint32_t *const volatile *>(&ka->out_cmps);
+            uint32_t *const o_hops = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 8)) : *const_cast<uint32_t *const volatile *>(&ka->out_hops);
+            uint32_t *const o_scanned = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 10)) : *const_cast<uint32_t *const volatile *>(&ka->out_scanned);
+            auto put = [&](uint32_t *dst, uint32_t v) {
+                if constexpr (STREAM) sys_store32(dst, v);
+                else *dst = v;
+            };
             for (uint32_t i = lane; i < p.k; i += 64) {
                 uint32_t id = 0xFFFFFFFFu;
                 float d = __builtin_inff();
@@ -1058,13 +1203,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     id = (uint32_t)e >> 1;
                     d = ord2f((uint32_t)(e >> 32));
                 }
-                o_ids[(u64)q * p.k + i] = id;
-                o_dists[(u64)q * p.k + i] = d;
+                put(o_ids + (u64)q * p.k + i, id);
+                put(reinterpret_cast<uint32_t *>(o_dists) + (u64)q * p.k + i, __float_as_uint(d));
             }
             if (lane == 0) {
-                if (o_cmps) o_cmps[q] = cmps;
-                if (o_hops) o_hops[q] = hops;
-                if (o_scanned) o_scanned[q] = scanned;
+                if (o_cmps) put(o_cmps + q, cmps);
+                if (o_hops) put(o_hops + q, hops);
+                if (o_scanned) put(o_scanned + q, scanned);
                 if constexpr (STATS) {
                     uint32_t *const o_traffic = *const_cast<uint32_t *const volatile *>(&ka->out_traffic);
                     const u64 t = *traffic;
@@ -1072,7 +1217,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     // every neighbour counted in cmps was scored on the f32 rows, but for those the screen dropped; + the entry point
                     *reinterpret_cast<uint4 *>(o_traffic + 4 * (u64)q) = make_uint4(coded, 1u + cmps - coded + passed, (uint32_t)(t >> 44) * 64u, 0u);
                 }
-                if (psize < p.k) atomicAdd(*const_cast<uint32_t *const volatile *>(&ka->counter) + 2, 1u);  // short queries of this launch
+                if (!STREAM && psize < p.k) atomicAdd(*const_cast<uint32_t *const volatile *>(&ka->counter) + 2, 1u);  // short queries of this launch
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
                     o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);
@@ -1091,6 +1236,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     o[13] = o[14] = o[15] = 0;
                 }
             }
+            if constexpr (STREAM) stream_finish(lane, psize < p.k);
         }
         block_sync();
     }
@@ -1131,10 +1277,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #ifndef ROAR_WPE_512
 #define ROAR_WPE_512 2
 #endif
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, bool GATED = false, bool STATS = false, bool PROT = false>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, int SRC = 0, bool STATS = false, bool PROT = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(NCH > 16 ? ROAR_WPE_512 : 3, NCH > 16 ? ROAR_WPE_512 : 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, GATED, STATS, PROT>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, SRC, STATS, PROT>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -1155,31 +1301,41 @@ const void *pick_form(const RoarKernelSel &s) {
         else
             return nullptr;
     }
+    if (s.stream) {  // batch-stream form: one wave per query, forgetful on-chip tag table, queries from a ring of submitted batches
+        if constexpr (MODE == VIS_LDS) {
+            if (s.waves != 1 || s.hub || s.gated || s.prof || s.stats || (s.protect && rp)) return nullptr;
+            if (s.protect) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 2, false, true>;
+            return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, 2>
+                      : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 2>;
+        } else {
+            return nullptr;
+        }
+    }
     if constexpr (MODE == VIS_LDS) {
         if (s.protect) {  // the forgetful table keeps the tags of pool members: one wave per query, pool in LDS, no hub bitmap / gate
             if (rp || s.waves != 1 || s.hub || s.gated) return nullptr;
-            if (s.stats) return s.prof ? nullptr : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, true, true>;
+            if (s.stats) return s.prof ? nullptr : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 0, true, true>;
             if (s.prof) {
                 if constexpr ((IP && NCH == 12) || (!IP && NCH == 8))
-                    return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true, false, false, false, true>;
+                    return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, true, false, 0, false, true>;
                 else
                     return nullptr;
             }
-            return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, false, true>;
+            return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 0, false, true>;
         }
     } else {
         if (s.protect) return nullptr;
     }
     if (s.stats) {  // one wave per query, counting what each query fetches (RoarSearchParams::out_traffic)
         if (s.prof || s.waves != 1 || s.gated || (s.hub && rp)) return nullptr;
-        if (s.hub) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, true, false, true>;
-        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, false, true>
-                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, false, true>;
+        if (s.hub) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, true, 0, true>;
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, 0, true>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 0, true>;
     }
     if (s.gated) {  // one wave per query, waiting for the host's rows-written counter (pageable host query blocks)
         if (s.hub || s.prof || s.waves != 1) return nullptr;
-        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, true>
-                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, true>;
+        return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, 1>
+                  : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 1>;
     }
     if (s.hub) {  // long pools: LDS pool, hub bitmap
         if (rp) return nullptr;

@@ -272,6 +272,10 @@ class IndexBipartite:
             C.c_void_p(st.cuda_stream)))
         return out
 
+    def OpenSearchStream(self, k, L_pq):
+        """roar_search_stream_open: a stream of batches served by workgroups that outlive a batch (include/roargraph_amd.h)."""
+        return SearchStream(self, k, L_pq)
+
     # ---- bipartite two-hop variant (index_bipartite.cpp:42-141, 235-356, 2045-2071) ---------------
     def Load(self, filename):
         """IndexBipartite::Load, index_bipartite.cpp:2060-2071"""
@@ -484,3 +488,69 @@ def normalize(arr):
             s = np.float32(s + v * v)
         arr[i] = arr[i] / np.sqrt(s, dtype=np.float32)
     return arr
+
+
+class SearchStream:
+    """ctypes mirror of roar_search_stream_* (device buffers: torch tensors in HBM).  The tensors of a submitted batch are kept alive
+    here until its ticket has been waited for."""
+
+    def __init__(self, index, k, L_pq):
+        self._lib = index._lib
+        self._index = index
+        self.k = int(k)
+        h = C.c_void_p()
+        capi.check(self._lib.roar_search_stream_open(index._h, int(k), int(L_pq), C.byref(h)))
+        self._h = h
+        self._keep = {}
+
+    def submit(self, queries, out=None):
+        """-> (ticket, out).  `queries` must be complete in device memory (synchronise its producer first)."""
+        import torch
+
+        nq = queries.shape[0]
+        dev = queries.device
+        if out is None:
+            out = dict(ids=torch.empty((nq, self.k), dtype=torch.int32, device=dev),
+                       dists=torch.empty((nq, self.k), dtype=torch.float32, device=dev),
+                       cmps=torch.empty(nq, dtype=torch.int32, device=dev),
+                       hops=torch.empty(nq, dtype=torch.int32, device=dev),
+                       scanned=torch.empty(nq, dtype=torch.int32, device=dev))
+        t = C.c_uint64()
+        capi.check(self._lib.roar_search_stream_submit(
+            self._h, C.c_void_p(queries.data_ptr()), nq, queries.shape[1] if queries.dim() == 2 else 0,
+            C.c_void_p(out["ids"].data_ptr()), C.c_void_p(out["dists"].data_ptr()), C.c_void_p(out["cmps"].data_ptr()),
+            C.c_void_p(out["hops"].data_ptr()), C.c_void_p(out["scanned"].data_ptr()), C.byref(t)))
+        if t.value:
+            self._keep[t.value] = (queries, out)
+        return t.value, out
+
+    def wait(self, ticket):
+        """-> queries of the batch that ended with fewer than k results"""
+        n = C.c_uint32()
+        capi.check(self._lib.roar_search_stream_wait(self._h, int(ticket), C.byref(n)))
+        self._keep.pop(int(ticket), None)
+        return n.value
+
+    def times(self, ticket):
+        a, b = C.c_uint64(), C.c_uint64()
+        capi.check(self._lib.roar_search_stream_times(self._h, int(ticket), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self, key):
+        v = C.c_int64()
+        capi.check(self._lib.roar_search_stream_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            capi.check(self._lib.roar_search_stream_close(h))
+            self._keep.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+

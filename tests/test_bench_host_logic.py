@@ -120,8 +120,16 @@ def test_emulated_share_of_8_block():
 
     # 10 000-query batch, 20 steps: one rank's 1 250-query share took 4.4 ms in all, six in flight; this run served 7.0 M QPS
     b = bench.share_of_8_block(10_000, 20, 4.4e-3, 8.6e-3, 6, 640, 7.0e6)
-    assert b["queries_per_launch"] == 1250 and b["launches_in_flight"] == 6 and b["workgroups_per_launch_cap"] == 640
+    assert b["queries_per_step"] == 1250 and b["launches_in_flight"] == 6 and b["workgroups_per_launch_cap"] == 640
     assert b["ms_per_step"] == pytest.approx(0.22) and b["ms_per_step_one_launch_at_a_time"] == pytest.approx(0.43)
     assert b["projected_value_8_gpus"] == pytest.approx(10_000 * 20 / 4.4e-3)
     assert b["projected_speedup_over_this_run"] == pytest.approx(10_000 * 20 / 4.4e-3 / 7.0e6)
-    assert "projection" in b["note"]
+    assert "projection" in b["note"] and b["regime"] == "6 launches in flight" and b["ms_per_step_batch_stream"] is None
+    # the same share through one batch stream in 3.9 ms: the better regime is the one projected from, and it is named
+    b = bench.share_of_8_block(10_000, 20, 4.4e-3, 8.6e-3, 6, 640, 7.0e6, 3.9e-3, {"kernel_launches_in_the_timed_region": 3})
+    assert b["regime"].startswith("one batch stream") and b["ms_per_step"] == pytest.approx(0.195)
+    assert b["ms_per_step_launches_in_flight"] == pytest.approx(0.22) and b["ms_per_step_batch_stream"] == pytest.approx(0.195)
+    assert b["projected_speedup_over_this_run"] == pytest.approx(10_000 * 20 / 3.9e-3 / 7.0e6)
+    # ... and a stream that is slower is reported but not projected from
+    b = bench.share_of_8_block(10_000, 20, 4.4e-3, 8.6e-3, 6, 640, 7.0e6, 5.0e-3, None)
+    assert b["regime"] == "6 launches in flight" and b["ms_per_step"] == pytest.approx(0.22)

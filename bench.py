@@ -601,6 +601,9 @@ def main():
                 wall_ = t.item()
             tt = [st_.times(t__) for t__ in tk]
             span_ms = (max(b_ for _, b_ in tt) - min(a_ for a_, _ in tt)) * 1e-6
+            t0_ = min(a_ for a_, _ in tt)
+            log("[stream timeline] us since the first query was taken, per step (first query taken, batch complete): "
+                + " ".join(f"({(a_ - t0_) / 1e3:.0f},{(b_ - t0_) / 1e3:.0f})" for a_, b_ in tt) + f"; wall {wall_ * 1e6:.0f} us")
             info_ = {"kernel_launches_in_the_timed_region": st_.info("launches") - launches0, "resident_workgroups": st_.info("resident_capacity"),
                      "times_wait_had_to_start_workgroups": st_.info("heals"), "screen": bool(st_.info("screen")),
                      "vis_entries": st_.info("vis_entries"), "lds_bytes": st_.info("lds_bytes")}

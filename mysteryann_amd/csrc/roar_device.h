@@ -5,10 +5,14 @@
 
 // ---- batch-stream form (roar_search_stream_*, roar_stream.cpp; kernel: SRC == 2 in roar_search_v2.h) -----------------------------
 // Workgroups do not belong to a launch's batch: they take queries from a ring of SUBMITTED batches, cross batch boundaries, and
-// leave when nothing published is left.  The host publishes a batch by writing its slot and then `tail`; the kernel reports a
-// finished batch in the slot's RoarStreamDone.  All three live in pinned (coherent) host memory; the per-batch counters
-// (RoarStreamCell) live in device memory, one per batch NUMBER -- never recycled while any workgroup is alive, so a late
-// workgroup can touch a counter of a long finished batch without harm.
+// leave when nothing published is left.  The host publishes a batch by writing its slot and then `tail` in PINNED HOST memory; the
+// kernel reports a finished batch in the slot's RoarStreamDone (also pinned).  A read of host memory is a PCIe round trip, and the
+// chip can only keep so many of them in flight (first form: every workgroup fetched every batch's slot itself -- 6 144 reads per
+// batch, 0.7 ms per batch whatever its size), so the workgroups keep what they have learnt in DEVICE memory (RoarStreamDev): ONE
+// workgroup fetches a batch's slot (a compare-and-swap on the batch's state word elects it) and leaves a copy for the others, and the
+// host's `tail` is looked at by one workgroup at a time, at most every few microseconds, and mirrored.  The per-batch counters
+// (RoarStreamCell) are indexed by batch NUMBER and never recycled while any workgroup is alive, so a late workgroup can touch the
+// counters of a long finished batch without harm.
 struct RoarStreamSlot {   // 64 bytes, ring position = batch number % ring; written by the host (seqlock: seq1 = 0 first, the fields, seq1 last)
     uint64_t queries;     // device pointers of the batch (out_cmps / out_hops / out_scanned may be 0)
     uint64_t out_ids, out_dists, out_cmps, out_hops, out_scanned;
@@ -17,7 +21,7 @@ struct RoarStreamSlot {   // 64 bytes, ring position = batch number % ring; writ
     uint32_t pad;
     uint32_t seq1;        // batch number + 1 (0 while the slot is being rewritten)
 };
-struct RoarStreamDone {   // 32 bytes, one per ring position; written by the kernel
+struct RoarStreamDone {   // 32 bytes, one per ring position; pinned host memory, written by the kernel
     uint64_t t_first;     // device wall clock (100 MHz) when the batch's first query was taken ...
     uint64_t t_done;      // ... and when its last query had its results in device memory
     uint32_t nshort;      // queries that returned fewer than k results
@@ -25,15 +29,28 @@ struct RoarStreamDone {   // 32 bytes, one per ring position; written by the ker
     uint32_t seq1_claimed;  // batch number + 1 once the batch's last query has been handed out (the host then starts no workgroups for it)
     uint32_t pad;
 };
-struct RoarStreamCtl {    // 64 bytes
-    uint32_t tail;        // batches published so far (host writes, workgroups read)
-    uint32_t exited;      // workgroups that have left, all launches of the stream together (workgroups add, host reads)
+struct RoarStreamCtl {    // 64 bytes, pinned host memory
+    uint32_t tail;        // batches published so far (host writes; a workgroup reads it when the device's mirror says "nothing left")
+    uint32_t exited;      // workgroups that have left: posted by every 64th one and by the last one alive (the host keeps the largest value seen)
     uint32_t pad[14];
 };
 struct RoarStreamCell {   // device memory, one per batch number
     unsigned long long done_short;  // low word: queries finished; high word: of those, short ones (one 64-bit add per query)
     uint32_t next;                  // next query of the batch to hand out (grows past nq: harmless)
-    uint32_t pad;
+    uint32_t state;                 // the batch's slot in RoarStreamDev::mirror: 0 not fetched, 1 being fetched, 2 there, 3 the host's slot already held a later batch
+};
+struct RoarStreamDev {    // device memory: what the workgroups have learnt from the host, shared among them.  One 128-byte line per word
+                          // that many workgroups touch at once (atomics and agent-scope loads on one line are served one after the other:
+                          // first form, everything in one line -- the last batch of a stream finished 3 ms late behind 3 000 leaving workgroups)
+    unsigned long long tail_time;   // 40 bits of the device wall clock when the last look at the host's tail came back << 24 | that tail
+    unsigned long long pad0[15];
+    unsigned long long started_exited;  // workgroups started << 32 | workgroups that have left (one 64-bit add each way)
+    unsigned long long pad1[15];
+    uint32_t checking;    // 1 while a workgroup is reading the host's tail (the others wait for its answer instead of asking themselves)
+    uint32_t pad2[31];
+    uint32_t frontier;    // every batch before this one has handed out all its queries (set by whoever takes a batch's last query)
+    uint32_t pad3[31];
+    RoarStreamSlot mirror[1];       // [ring] copies of the host's slots, each written once per batch by the workgroup that fetched it
 };
 
 struct RoarSearchParams {
@@ -113,8 +130,10 @@ struct RoarSearchParams {
     const RoarStreamSlot *s_slots;
     RoarStreamDone *s_done;
     RoarStreamCell *s_cells;
+    RoarStreamDev *s_dev;
     uint32_t s_ring;
     uint32_t s_start;
+    uint32_t s_tail;  // batches published when this launch was made
     uint32_t off_stream;
 };
 

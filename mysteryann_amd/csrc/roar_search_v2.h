@@ -603,12 +603,17 @@ __device__ __forceinline__ void screen8_query(float *lq, uint32_t dim, int lane,
 // the next batches' first ones without any launch boundary (the loop being split: tests/test_search_roargraph.cpp:202-212).
 // Its block in LDS (32 words at p.off_stream): 0-15 copy of the slot it works on, 16 `want` = the batch number it takes queries from,
 // 17 batches published as last seen, 18 batch number + 1 of the copy (0: none).
-// Memory the host or another launch may rewrite between batches (slots, query rows) is read with system-scope loads -- a workgroup
-// that lives across batches never passes the L2 invalidate of a kernel start -- and results are stored write-through (system scope),
-// so that "every query of the batch has finished" (one 64-bit add per query on the batch's counter cell) means "its results are in
-// device memory" for whoever the host lets read them next.
+// Host memory is touched by ONE workgroup per batch (the slot) and by one workgroup at a time (the host's `tail`): what they read is
+// shared through device memory (RoarStreamDev; roar_device.h says why).  Memory the host or another launch may rewrite between batches
+// (query rows) is read with system-scope loads -- a workgroup that lives across batches never passes the L2 invalidate of a kernel
+// start -- and results are stored write-through (system scope), so that "every query of the batch has finished" (one 64-bit add per
+// query on the batch's counter cell) means "its results are in device memory" for whoever the host lets read them next.  No ACQUIRE /
+// SEQ_CST atomics anywhere here: at system scope they are a `buffer_inv sc0 sc1` -- every workgroup of the XCD loses its L2 lines, hub
+// rows and all; every value that something depends on is waited for explicitly.
 __device__ __forceinline__ uint32_t sys_load32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void sys_store32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ uint32_t dev_load32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dev_store32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 lds_ptr(const volatile uint32_t *sl, int w) { return ((u64)sl[w + 1] << 32) | (u64)sl[w]; }
 
 // What the stream's bookkeeping needs from the kernel arguments is read from the kernel-argument segment where it is used, once or twice
@@ -618,6 +623,7 @@ struct StreamArgs {
     const RoarStreamSlot *slots;
     RoarStreamDone *done;
     RoarStreamCell *cells;
+    RoarStreamDev *dev;
     uint32_t ring_mask;
     volatile uint32_t *sl;
 };
@@ -630,6 +636,7 @@ __device__ __forceinline__ StreamArgs stream_args() {
     a.slots = *const_cast<const RoarStreamSlot *const volatile *>(&ka->s_slots);
     a.done = *const_cast<RoarStreamDone *const volatile *>(&ka->s_done);
     a.cells = *const_cast<RoarStreamCell *const volatile *>(&ka->s_cells);
+    a.dev = *const_cast<RoarStreamDev *const volatile *>(&ka->s_dev);
     a.ring_mask = *const_cast<const uint32_t volatile *>(&ka->s_ring) - 1u;
     a.sl = reinterpret_cast<volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_stream));
 #else
@@ -638,28 +645,69 @@ __device__ __forceinline__ StreamArgs stream_args() {
     return a;
 }
 
-// -> true: q = a query of batch sl[16], whose slot is in sl[0..15]; false: nothing published is left and the workgroup has signed
-// off (RoarStreamCtl::exited).  Wave-uniform.
+constexpr uint32_t STREAM_TAIL_LOOK_TICKS = 500;  // 5 us of the 100 MHz device clock: how old the device's copy of the host's tail may be
+// RoarStreamDev::tail_time = 40 bits of the device clock (never 0: 0 = "not a look at the host") << 24 | the tail (at most 2^16 batches an epoch)
+__device__ __forceinline__ unsigned long long stream_clock40() {
+    const unsigned long long c = (unsigned long long)wall_clock64() & 0xFFFFFFFFFFull;
+    return c ? c : 1ull;
+}
+
+// -> true: q = a query of batch sl[16], whose slot is in sl[0..15]; false: nothing published is left and the workgroup has counted
+// itself out (RoarStreamDev::started_exited).  Wave-uniform.
 __device__ __forceinline__ bool stream_take(int lane, uint32_t &q) {
     const StreamArgs a = stream_args();
     volatile uint32_t *const sl = a.sl;
     for (;;) {
         const uint32_t want = sl[16];
-        if (want >= sl[17]) {  // past what this workgroup has seen published: look again
+        if (want >= sl[17]) {  // past what this workgroup knows to be published
             uint32_t t = 0;
-            if (lane == 0) t = __hip_atomic_load(&a.ctl->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) {
+                // The device's copy of the host's tail (+ when it was read): good if it shows more batches, or if it is fresh.  Else ONE
+                // workgroup reads the host's word (a PCIe round trip) and the others wait for its answer -- they neither ask themselves
+                // nor leave on a stale copy (a fifth of a freshly launched grid was gone, in the first form, before the batches the host
+                // published microseconds later were seen).
+                for (;;) {
+                    const unsigned long long tt = __hip_atomic_load(&a.dev->tail_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t = (uint32_t)tt & 0xFFFFFFu;
+                    if (t > want) break;
+                    if ((tt >> 24) != 0 && ((stream_clock40() - (tt >> 24)) & 0xFFFFFFFFFFull) <= STREAM_TAIL_LOOK_TICKS) break;
+                    if (dev_load32(&a.dev->checking) == 0u && atomicCAS(&a.dev->checking, 0u, 1u) == 0u) {
+                        const uint32_t h = sys_load32(&a.ctl->tail);  // (one workgroup at a time: the copy is simply replaced, the host's tail only grows)
+                        (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)h);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        (void)atomicExch(&a.dev->checking, 0u);
+                        t = h > t ? h : t;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+            }
             t = uni(t);
             if (want >= t) {
-                // Nothing left.  Sign off, then look ONCE more: the host publishes a batch and THEN reads `exited` to decide whether
-                // workgroups must be launched for it -- one of the two sees the other's write.  (roar_search_stream_wait also starts
-                // workgroups when it finds none alive: a lost race costs time, never a batch.)
+                // Nothing left.  Leave -- unless this is the last workgroup alive: that one tells the host how many have left and then
+                // looks at the host's tail itself (the host publishes a batch and THEN reads `exited` to decide whether workgroups
+                // must be started for it: one of the two sees the other's write; roar_search_stream_wait also starts workgroups when
+                // it finds a batch pending and too few alive: a lost race costs time, never a batch).  The host's count of who is
+                // alive is refreshed by every 64th workgroup to leave (a posted write each), by the last one, and with every batch.
+                uint32_t again = t;
                 if (lane == 0) {
-                    (void)__hip_atomic_fetch_add(&a.ctl->exited, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
-                    t = __hip_atomic_load(&a.ctl->tail, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long se = atomicAdd(&a.dev->started_exited, 1ull) + 1ull;
+                    const uint32_t ex = (uint32_t)se, started = (uint32_t)(se >> 32);
+                    if (ex >= started) {
+                        sys_store32(&a.ctl->exited, ex);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the count is on its way before the tail is sampled)
+                        again = sys_load32(&a.ctl->tail);
+                        if (again > t) {
+                            (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)again);
+                            (void)atomicAdd(&a.dev->started_exited, ~0ull);  // (back in: one fewer has left)
+                        }
+                    } else if ((ex & 63u) == 0u) {
+                        sys_store32(&a.ctl->exited, ex);
+                    }
                 }
-                t = uni(t);
-                if (want >= t) return false;
-                if (lane == 0) (void)__hip_atomic_fetch_sub(&a.ctl->exited, 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                again = uni(again);
+                if (want >= again) return false;
+                t = again;
             }
             if (lane == 0) sl[17] = t;
             wave_sync();
@@ -667,31 +715,68 @@ __device__ __forceinline__ bool stream_take(int lane, uint32_t &q) {
         uint32_t idx = 0;
         if (lane == 0) idx = atomicAdd(&a.cells[want].next, 1u);
         idx = uni(idx);
-        if (sl[18] != want + 1u) {  // the copy is another batch's: fetch the slot (64 bytes over PCIe), seqlock-checked
-            const RoarStreamSlot *slot = a.slots + (want & a.ring_mask);
-            uint32_t w = 0;
-            if (lane < 16) w = sys_load32(reinterpret_cast<const uint32_t *>(slot) + lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the second look at seq1 must be sampled after the fields)
-            uint32_t again = 0;
-            if (lane == 0) again = sys_load32(&slot->seq1);
-            const bool ok = lane_u32(w, 15) == want + 1u && uni(again) == want + 1u;
-            if (lane < 16) sl[lane] = w;
+        if (idx != 0xFFFFFFFFu && sl[18] != want + 1u) {  // this workgroup's copy is another batch's: the slot from the device's mirror, fetched from the host by ONE workgroup
+            uint32_t st = 0;
+            if (lane == 0) {
+                st = dev_load32(&a.cells[want].state);
+                if (st == 0) st = atomicCAS(&a.cells[want].state, 0u, 1u);
+            }
+            st = uni(st);
+            RoarStreamSlot *const mir = a.dev->mirror + (want & a.ring_mask);
+            if (st == 0) {  // elected: the slot over PCIe (64 bytes), seqlock-checked, then into the mirror
+                const RoarStreamSlot *slot = a.slots + (want & a.ring_mask);
+                uint32_t w = 0;
+                if (lane < 16) w = sys_load32(reinterpret_cast<const uint32_t *>(slot) + lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the second look at seq1 must be sampled after the fields)
+                uint32_t seq_again = 0;
+                if (lane == 0) seq_again = sys_load32(&slot->seq1);
+                const bool ok = lane_u32(w, 15) == want + 1u && uni(seq_again) == want + 1u;
+                if (ok && lane < 16) dev_store32(reinterpret_cast<uint32_t *>(mir) + lane, w);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) (void)atomicExch(&a.cells[want].state, ok ? 2u : 3u);
+                st = ok ? 2u : 3u;
+            } else {
+                while (st == 1u) {  // (the elected workgroup is two PCIe round trips away from done)
+                    __builtin_amdgcn_s_sleep(32);
+                    if (lane == 0) st = dev_load32(&a.cells[want].state);
+                    st = uni(st);
+                }
+            }
+            bool ok = st == 2u;
+            if (ok) {  // (a mirror entry is rewritten only for the batch `ring` numbers later, i.e. after this one is complete: checked)
+                uint32_t w = 0;
+                if (lane < 16) w = dev_load32(reinterpret_cast<const uint32_t *>(mir) + lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t seq_again = 0;
+                if (lane == 0) seq_again = dev_load32(&mir->seq1);
+                ok = lane_u32(w, 15) == want + 1u && uni(seq_again) == want + 1u;
+                if (lane < 16) sl[lane] = w;
+            }
             if (lane == 0) sl[18] = ok ? want + 1u : 0u;
             wave_sync();
-            if (!ok) {  // the slot already holds a later batch: batch `want` was complete long ago
+            if (!ok) {  // the slot already held a later batch: batch `want` was complete long ago
                 if (lane == 0) sl[16] = want + 1u;
                 wave_sync();
                 continue;
             }
         }
-        if (idx >= sl[12]) {  // the batch has no query left to hand out: on to the next one
-            if (lane == 0) sl[16] = want + 1u;
+        if (idx >= sl[12]) {
+            // The batch has no query left to hand out: on to the first batch that may have one -- the frontier the others have
+            // reached, not simply the next one (with 1 250-query batches the chip's workgroups span two or three batches, and walking
+            // them one by one is as many futile adds on hot words per dequeue)
+            if (lane == 0) {
+                const uint32_t f = dev_load32(&a.dev->frontier);
+                sl[16] = f > want + 1u ? f : want + 1u;
+            }
             wave_sync();
             continue;
         }
         if (idx == 0 && lane == 0)
             __hip_atomic_store(&a.done[want & a.ring_mask].t_first, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (idx + 1u == sl[12] && lane == 0) sys_store32(&a.done[want & a.ring_mask].seq1_claimed, want + 1u);
+        if (idx + 1u == sl[12] && lane == 0) {  // the batch's last query: nothing left in it for anybody else
+            (void)atomicMax(&a.dev->frontier, want + 1u);
+            sys_store32(&a.done[want & a.ring_mask].seq1_claimed, want + 1u);
+        }
         q = idx;
         return true;
     }
@@ -710,7 +795,9 @@ __device__ __forceinline__ void stream_finish(int lane, bool was_short) {
             RoarStreamDone *d = a.done + (want & a.ring_mask);
             __hip_atomic_store(&d->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             sys_store32(&d->nshort, (uint32_t)(now >> 32));
-            __hip_atomic_store(&d->seq1_done, want + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            sys_store32(&a.ctl->exited, (uint32_t)__hip_atomic_load(&a.dev->started_exited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (who has left by now)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the record's fields before its seq1_done; every result store of the batch
+            sys_store32(&d->seq1_done, want + 1u);            //  was acknowledged before its workgroup counted the query)
         }
     }
 }
@@ -783,8 +870,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
     if constexpr (STREAM) {
         if (lane == 0) {
-            volatile uint32_t *const sl = stream_args().sl;
-            sl[16] = p.s_start, sl[17] = 0u, sl[18] = 0u;
+            const StreamArgs a = stream_args();
+            a.sl[16] = p.s_start, a.sl[17] = p.s_tail, a.sl[18] = 0u;
+            (void)atomicAdd(&a.dev->started_exited, 1ull << 32);
+            // (what this launch was told at its start, sl[17], is not shared: the device's copy of the host's tail is written by looks at the host only)
         }
         wave_sync();
     }

@@ -11,12 +11,17 @@
 //   * the workgroup that finishes a batch's last query (a second counter in the cell) writes the batch's completion record to pinned
 //     host memory; roar_search_stream_wait polls it.  Results are bit-identical to separate launches (the same search code).
 //
-// Nothing spins waiting for the host: a workgroup that finds nothing published signs off (RoarStreamCtl::exited) and exits, so a stream
-// that is open but idle holds no part of the chip, and no kernel can outlive the work it was given.  submit() therefore tops the
-// workgroups up: it knows how many it has launched, reads how many have left, and launches min(resident capacity, queries pending) -
-// alive more on one of its own HIP streams.  The race "the last workgroups sign off while a batch is being published" is closed on
-// both sides (publish, THEN read `exited`; sign off, THEN look at `tail` once more) and, belt and braces, wait() launches workgroups
-// itself when it finds a batch pending and nobody alive.
+// Nothing spins waiting for the host: a workgroup that finds nothing published counts itself out and exits, so a stream that is open
+// but idle holds no part of the chip, and no kernel can outlive the work it was given.  submit() therefore tops the workgroups up: it
+// knows how many it has launched, reads how many have left (every leaving workgroup posts the running count to pinned memory), and
+// launches min(room on the chip, queries nobody has taken yet) more on one of its own HIP streams.  The race "the last workgroup
+// leaves while a batch is being published" is closed on both sides (publish, THEN read `exited`; post the count, THEN look at the
+// host's `tail` once more) and, belt and braces, wait() starts workgroups itself when it finds a batch pending and nobody -- or too few
+// -- alive.
+//
+// PCIe is kept out of the workgroups' way (roar_device.h): a batch's slot is fetched from pinned memory by ONE workgroup and mirrored in
+// device memory for the others, the host's `tail` is read by one workgroup at a time and mirrored, results and counters live in device
+// memory; per batch the bus carries two reads and four small posted writes.
 //
 // Counter cells are indexed by batch NUMBER and never reused while a workgroup may be alive (a late workgroup may touch the cell of a
 // long finished batch): after `cap` batches submit() drains the stream -- every batch complete, every launch finished -- and zeroes
@@ -42,6 +47,8 @@ struct roar_stream {
     RoarStreamSlot *slots = nullptr;
     RoarStreamDone *done = nullptr;
     RoarStreamCell *cells = nullptr;  // device memory
+    RoarStreamDev *dev = nullptr;     // device memory: what the workgroups share (mirrors of the host's tail and slots)
+    uint32_t max_exited = 0;          // largest RoarStreamCtl::exited seen (posted writes of several workgroups may land out of order)
     uint32_t submitted = 0;   // batch numbers handed out in this epoch
     uint32_t completed = 0;   // every batch < completed is known complete
     uint64_t pending_q = 0;   // queries of the batches in [completed, submitted)
@@ -70,9 +77,12 @@ constexpr double WAIT_TIMEOUT_S = 60.0;
 
 size_t pin_bytes(const roar_stream *s) { return sizeof(RoarStreamCtl) + (size_t)s->ring * (sizeof(RoarStreamSlot) + sizeof(RoarStreamDone)); }
 
-uint32_t alive(const roar_stream *s) {
+size_t dev_bytes(const roar_stream *s) { return sizeof(RoarStreamDev) + (size_t)s->ring * sizeof(RoarStreamSlot); }
+
+uint32_t alive(roar_stream *s) {
     const uint32_t ex = *reinterpret_cast<volatile uint32_t *>(&s->ctl->exited);
-    return (uint32_t)(s->launched - (uint64_t)ex);
+    if (ex > s->max_exited && (uint64_t)ex <= s->launched) s->max_exited = ex;
+    return (uint32_t)(s->launched - (uint64_t)s->max_exited);
 }
 
 // g more workgroups, on a HIP stream of the stream's own whose last launch has finished (launches on one HIP stream run one after the
@@ -115,6 +125,7 @@ int launch_wgs(roar_stream *s, uint32_t g) {
             ln = &s->lanes.back();
         }
     }
+    s->plan.p.s_tail = s->submitted;
     s->plan.p.s_start = s->claimed;  // (every query of the batches before it has been handed out: nothing there for a new workgroup)
     const int rc = roar_launch_search(&s->plan.p, &s->plan.sel, g, ln->st);
     if (rc != 0) {
@@ -159,13 +170,17 @@ bool batch_done(roar_stream *s, uint32_t b) {  // (a batch may finish before an 
 
 // workgroups for what nobody has taken yet: up to the chip's capacity, never more than there are such queries (known per batch: the
 // workgroup that takes a batch's last query says so in the batch's record)
-int top_up(roar_stream *s, bool heal) {
+// (from wait(): only when nobody is alive, or when a sixteenth of the chip could be put to work -- the host's view of who is alive lags)
+int top_up(roar_stream *s, bool from_wait) {
     const uint32_t live = alive(s);
-    if (heal && live != 0) return ROAR_OK;
     const uint64_t room = s->R > live ? s->R - live : 0;
-    const uint64_t g = std::min<uint64_t>(room, heal ? std::max<uint64_t>(s->unclaimed_q, 1) : s->unclaimed_q);
+    uint64_t g = std::min<uint64_t>(room, s->unclaimed_q);
+    if (from_wait) {
+        if (live == 0 && s->pending_q) g = std::max<uint64_t>(g, 1);
+        else if (g < std::max<uint32_t>(s->R / 16, 1)) g = 0;
+    }
     if (g == 0) return ROAR_OK;
-    if (heal) s->n_heals++;
+    if (from_wait) s->n_heals++;
     return launch_wgs(s, (uint32_t)g);
 }
 
@@ -180,7 +195,7 @@ int wait_for(roar_stream *s, std::unique_lock<std::mutex> &lk, Pred pred, const 
         if (pred()) return ROAR_OK;
         if (s->broken) return fail(ROAR_ERR_DEVICE, "search stream: an earlier call failed; close the stream");
         if ((++spins & 0x3FFu) == 0) {
-            if (s->pending_q && alive(s) == 0) {
+            if (s->pending_q) {
                 int e = top_up(s, true);
                 if (e) return e;
             }
@@ -205,12 +220,14 @@ int reset_epoch(roar_stream *s, std::unique_lock<std::mutex> &lk) {
     for (auto &c : s->lanes)
         if (c.used) HIP_TRY(hipStreamSynchronize(c.st));
     HIP_TRY(hipMemset(s->cells, 0, (size_t)s->cap * sizeof(RoarStreamCell)));
+    HIP_TRY(hipMemset(s->dev, 0, dev_bytes(s)));
     HIP_TRY(hipDeviceSynchronize());
     memset(s->pin, 0, pin_bytes(s));
     std::atomic_thread_fence(std::memory_order_seq_cst);
     s->epoch_base += s->submitted;
     s->submitted = s->completed = s->claimed = 0;
     s->launched = 0;
+    s->max_exited = 0;
     s->pending_q = s->unclaimed_q = 0;
     s->nq_of.clear();
     s->n_resets++;
@@ -250,6 +267,7 @@ int roar_search_stream_open(roar_index *idx, uint32_t k, uint32_t L_pq, roar_str
     auto bail = [&](int code) {
         if (s->pin) (void)hipHostFree(s->pin);
         if (s->cells) (void)hipFree(s->cells);
+        if (s->dev) (void)hipFree(s->dev);
         delete s;
         return code;
     };
@@ -263,7 +281,8 @@ int roar_search_stream_open(roar_index *idx, uint32_t k, uint32_t L_pq, roar_str
     s->slots = reinterpret_cast<RoarStreamSlot *>(s->pin + sizeof(RoarStreamCtl));
     s->done = reinterpret_cast<RoarStreamDone *>(s->pin + sizeof(RoarStreamCtl) + (size_t)s->ring * sizeof(RoarStreamSlot));
     if (roar_dev_malloc((void **)&s->cells, (size_t)s->cap * sizeof(RoarStreamCell)) != hipSuccess ||
-        hipMemset(s->cells, 0, (size_t)s->cap * sizeof(RoarStreamCell)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        hipMemset(s->cells, 0, (size_t)s->cap * sizeof(RoarStreamCell)) != hipSuccess || roar_dev_malloc((void **)&s->dev, dev_bytes(s)) != hipSuccess ||
+        hipMemset(s->dev, 0, dev_bytes(s)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         return bail(fail(ROAR_ERR_DEVICE, "search stream: out of device memory"));
     }
@@ -303,6 +322,7 @@ int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t
         p.s_slots = reinterpret_cast<const RoarStreamSlot *>(s->pin_dev + sizeof(RoarStreamCtl));
         p.s_done = reinterpret_cast<RoarStreamDone *>(s->pin_dev + sizeof(RoarStreamCtl) + (size_t)s->ring * sizeof(RoarStreamSlot));
         p.s_cells = s->cells;
+        p.s_dev = s->dev;
         p.s_ring = s->ring;
         p.nq = 0;
         s->R = std::max<uint32_t>(s->plan.grid, 1);
@@ -436,6 +456,7 @@ int roar_search_stream_close(roar_stream *s) {
         (void)hipStreamDestroy(c.st);
     }
     (void)hipFree(s->cells);
+    (void)hipFree(s->dev);
     (void)hipHostFree(s->pin);
     delete s;
     return ROAR_OK;

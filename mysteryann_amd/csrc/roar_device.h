@@ -32,12 +32,14 @@ struct RoarStreamDone {   // 32 bytes, one per ring position; pinned host memory
 struct RoarStreamCtl {    // 64 bytes, pinned host memory
     uint32_t tail;        // batches published so far (host writes; a workgroup reads it when the device's mirror says "nothing left")
     uint32_t exited;      // workgroups that have left: posted by every 64th one and by the last one alive (the host keeps the largest value seen)
-    uint32_t pad[14];
+    uint32_t error;       // != 0: a workgroup gave up waiting for another one (2 s of device clock; never seen outside fault injection) -- the
+                          // host fails the stream instead of waiting for a kernel that spins: 1 slot fetch, 2 batch count, 3 tail look
+    uint32_t pad[13];
 };
 struct RoarStreamCell {   // device memory, one per batch number
     unsigned long long done_short;  // low word: queries finished; high word: of those, short ones (one 64-bit add per query)
     uint32_t next;                  // next query of the batch to hand out (grows past nq: harmless)
-    uint32_t state;                 // the batch's slot in RoarStreamDev::mirror: 0 not fetched, 1 being fetched, 2 there, 3 the host's slot already held a later batch
+    uint32_t pad;                   // (NOTHING that is merely LOADED may live in these lines: see RoarStreamDev::state)
 };
 struct RoarStreamDev {    // device memory: what the workgroups have learnt from the host, shared among them.  One 128-byte line per word
                           // that many workgroups touch at once (atomics and agent-scope loads on one line are served one after the other:
@@ -50,7 +52,17 @@ struct RoarStreamDev {    // device memory: what the workgroups have learnt from
     uint32_t pad2[31];
     uint32_t frontier;    // every batch before this one has handed out all its queries (set by whoever takes a batch's last query)
     uint32_t pad3[31];
-    RoarStreamSlot mirror[1];       // [ring] copies of the host's slots, each written once per batch by the workgroup that fetched it
+    unsigned long long take_ticks;  // device clock ticks workgroups have spent in stream_next (count + take), all of them together ...
+    unsigned long long take_calls;  // ... over this many calls (info keys "take_ns_total" / "take_calls": what a dequeue costs)
+    unsigned long long busy_ticks;  // ... and between a take and the end of its query's search (info key "busy_ns_total")
+    unsigned long long pad4[13];
+    // Per batch number: its entry of `mirror` is 0 not fetched, 1 being fetched, 2 there, 3 the host's slot already held a later batch.
+    // Its own array, NOT a word of the batch's counter cell: a line that takes millions of atomic adds a second must not also be
+    // LOADED by every workgroup -- each load puts a copy of the line into an XCD's L2 that the next add has to chase out again, and
+    // that traffic slows every memory access of the chip, not the loads (measured: one load of the cell's line per query made every
+    // hop of every search 20-30 % slower, 9.5 -> 7.6 M QPS at L_pq = 30; extra adds on lines nobody loads cost nothing).
+    uint32_t state[65536];
+    RoarStreamSlot mirror[1];       // [cap] copies of the host's slots by batch NUMBER, each written once, by the workgroup that fetched it (state 2: there for good)
 };
 
 struct RoarSearchParams {
@@ -134,6 +146,8 @@ struct RoarSearchParams {
     uint32_t s_ring;
     uint32_t s_start;
     uint32_t s_tail;  // batches published when this launch was made
+    uint32_t s_flags; // measurement switches (environment ROAR_STREAM_FLAGS): 1 the last finisher reports a batch (an add everybody waits for) instead of
+                      // the taker of its last query polling; 2 no fetching of slots ahead; 4 no t_first / claimed records
     uint32_t off_stream;
 };
 

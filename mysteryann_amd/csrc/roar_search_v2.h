@@ -625,6 +625,7 @@ struct StreamArgs {
     RoarStreamCell *cells;
     RoarStreamDev *dev;
     uint32_t ring_mask;
+    uint32_t flags;
     volatile uint32_t *sl;
 };
 __device__ __forceinline__ StreamArgs stream_args() {
@@ -638,6 +639,7 @@ __device__ __forceinline__ StreamArgs stream_args() {
     a.cells = *const_cast<RoarStreamCell *const volatile *>(&ka->s_cells);
     a.dev = *const_cast<RoarStreamDev *const volatile *>(&ka->s_dev);
     a.ring_mask = *const_cast<const uint32_t volatile *>(&ka->s_ring) - 1u;
+    a.flags = *const_cast<const uint32_t volatile *>(&ka->s_flags);
     a.sl = reinterpret_cast<volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_stream));
 #else
     a = StreamArgs{};  // (host pass of the compiler: never executed)
@@ -645,6 +647,7 @@ __device__ __forceinline__ StreamArgs stream_args() {
     return a;
 }
 
+constexpr unsigned long long STREAM_SPIN_LIMIT_TICKS = 200000000ull;  // 2 s: a workgroup waiting for ANOTHER workgroup gives up (RoarStreamCtl::error)
 constexpr uint32_t STREAM_TAIL_LOOK_TICKS = 500;  // 5 us of the 100 MHz device clock: how old the device's copy of the host's tail may be
 // RoarStreamDev::tail_time = 40 bits of the device clock (never 0: 0 = "not a look at the host") << 24 | the tail (at most 2^16 batches an epoch)
 __device__ __forceinline__ unsigned long long stream_clock40() {
@@ -652,153 +655,240 @@ __device__ __forceinline__ unsigned long long stream_clock40() {
     return c ? c : 1ull;
 }
 
-// -> true: q = a query of batch sl[16], whose slot is in sl[0..15]; false: nothing published is left and the workgroup has counted
-// itself out (RoarStreamDev::started_exited).  Wave-uniform.
-__device__ __forceinline__ bool stream_take(int lane, uint32_t &q) {
+// The workgroup has run past the batches it knows to be published (`want`): -> the number of batches published now, or 0 when
+// nothing is left and the workgroup has counted itself out (it must then leave).  Lane 0's view, made uniform by the caller.
+__device__ __forceinline__ uint32_t stream_more(const StreamArgs &a, uint32_t want) {
+    // The device's copy of the host's tail (+ when it was read): good if it shows more batches, or if it is fresh.  Else ONE workgroup
+    // reads the host's word (a PCIe round trip) and the others wait for its answer -- they neither ask themselves nor leave on a
+    // stale copy (a fifth of a freshly launched grid was gone, in the first form, before the batches the host published
+    // microseconds later were seen).
+    uint32_t t = 0;
+    const unsigned long long spin0 = (unsigned long long)wall_clock64();
+    for (;;) {
+        const unsigned long long tt = __hip_atomic_load(&a.dev->tail_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (uint32_t)tt & 0xFFFFFFu;
+        if (t > want) return t;
+        if ((unsigned long long)wall_clock64() - spin0 > STREAM_SPIN_LIMIT_TICKS) {
+            sys_store32(&a.ctl->error, 3u);
+            break;
+        }
+        if ((tt >> 24) != 0 && ((stream_clock40() - (tt >> 24)) & 0xFFFFFFFFFFull) <= STREAM_TAIL_LOOK_TICKS) break;
+        if (dev_load32(&a.dev->checking) == 0u && atomicCAS(&a.dev->checking, 0u, 1u) == 0u) {
+            const uint32_t h = sys_load32(&a.ctl->tail);  // (one workgroup at a time: the copy is simply replaced, the host's tail only grows)
+            (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)h);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)atomicExch(&a.dev->checking, 0u);
+            t = h > t ? h : t;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (t > want) return t;
+    // Nothing left.  Leave -- unless this is the last workgroup alive: that one tells the host how many have left and then looks at the
+    // host's tail itself (the host publishes a batch and THEN reads `exited` to decide whether workgroups must be started for it: one
+    // of the two sees the other's write; roar_search_stream_wait also starts workgroups when it finds a batch pending and too few
+    // alive: a lost race costs time, never a batch).  The host's count of who is alive is refreshed by every 64th workgroup to leave
+    // (a posted write each), by the last one, and with every batch.
+    const unsigned long long se = atomicAdd(&a.dev->started_exited, 1ull) + 1ull;
+    const uint32_t ex = (uint32_t)se, started = (uint32_t)(se >> 32);
+    if (ex >= started) {
+        sys_store32(&a.ctl->exited, ex);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the count is on its way before the tail is sampled)
+        const uint32_t again = sys_load32(&a.ctl->tail);
+        if (again > want) {
+            (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)again);
+            (void)atomicAdd(&a.dev->started_exited, ~0ull);  // (back in: one fewer has left)
+            return again;
+        }
+    } else if ((ex & 63u) == 0u) {
+        sys_store32(&a.ctl->exited, ex);
+    }
+    return 0u;
+}
+
+// Batch b's slot: host memory -> the device's mirror, by the workgroup that wins the election on the batch's state word (two PCIe round
+// trips: the 64 bytes, then seq1 once more -- the host's seqlock).  -> 0 somebody else has it in hand (or had), 2 fetched (w = the slot,
+// lanes 0-15), 3 the host's slot already held a later batch.  Wave-uniform.
+__device__ __forceinline__ uint32_t stream_fetch(const StreamArgs &a, int lane, uint32_t b, uint32_t &w) {
+    uint32_t st = 0;
+    if (lane == 0) st = atomicCAS(&a.dev->state[b], 0u, 1u);
+    if (uni(st) != 0u) return 0u;
+    const RoarStreamSlot *slot = a.slots + (b & a.ring_mask);
+    w = 0;
+    if (lane < 16) w = sys_load32(reinterpret_cast<const uint32_t *>(slot) + lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the second look at seq1 must be sampled after the fields)
+    uint32_t seq_again = 0;
+    if (lane == 0) seq_again = sys_load32(&slot->seq1);
+    const bool ok = lane_u32(w, 15) == b + 1u && uni(seq_again) == b + 1u;
+    if (ok && lane < 16) dev_store32(reinterpret_cast<uint32_t *>(a.dev->mirror + b) + lane, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) (void)atomicExch(&a.dev->state[b], ok ? 2u : 3u);
+    return ok ? 2u : 3u;
+}
+
+// One call per query: count the query that has just finished (`finish`: its result stores have been ISSUED, write-through) and take
+// the next one.  -> true: q = a query of batch sl[16], whose slot is in sl[0..15]; false: nothing published is left and the workgroup
+// has counted itself out (RoarStreamDev::started_exited).  Wave-uniform.
+//
+// What this costs is dependent round trips to device memory at agent scope -- ~4 us each while the chip is saturated with row gathers,
+// against ~450 us for a query -- so they are counted: the first form (take, slot, finish as separate steps: eight of them per
+// 1 250-query batch boundary) handed queries out 10 % slower than the per-launch form.  Here: the next take travels WITH the result
+// stores of the finished query (one wait for both); a take is ONE bundle of independent requests {add on the batch's `next`, the batch's
+// state word and mirrored slot if this workgroup has not got them, the frontier}; a finished query is counted with an add that nobody
+// waits for -- the workgroup that took the batch's LAST query polls the counter when its own query is done and reports the batch
+// (three or four workgroups of 3 072 poll at any time with 1 250-query batches).  A workgroup that stays within a batch: one round
+// trip per query, as the per-launch form; across a batch boundary: two.
+__device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_short, uint32_t &q) {
     const StreamArgs a = stream_args();
     volatile uint32_t *const sl = a.sl;
-    for (;;) {
-        const uint32_t want = sl[16];
-        if (want >= sl[17]) {  // past what this workgroup knows to be published
-            uint32_t t = 0;
-            if (lane == 0) {
-                // The device's copy of the host's tail (+ when it was read): good if it shows more batches, or if it is fresh.  Else ONE
-                // workgroup reads the host's word (a PCIe round trip) and the others wait for its answer -- they neither ask themselves
-                // nor leave on a stale copy (a fifth of a freshly launched grid was gone, in the first form, before the batches the host
-                // published microseconds later were seen).
+    uint32_t c = sl[16];
+    uint32_t idx = 0, st = 0, f = 0, w = 0;
+    bool have = false;  // a bundle for batch c has been issued (idx, st, f, w)
+    auto bundle = [&]() {
+        const bool need = sl[18] != c + 1u;
+        if (lane == 0) {
+            idx = atomicAdd(&a.cells[c].next, 1u);
+            f = dev_load32(&a.dev->frontier);
+            if (need) st = (a.flags & 128u) ? __builtin_nontemporal_load(&a.dev->state[c]) : dev_load32(&a.dev->state[c]);
+        }
+        if (need && lane < 16)
+            w = (a.flags & 128u) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane)
+                                 : dev_load32(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane);
+        have = true;
+    };
+    if (finish && (a.flags & 32u)) {  // (measurement: every take goes the long way -- the slot is read from the mirror again)
+        if (lane == 0) sl[18] = 0u;
+        wave_sync();
+    }
+    if (finish && (a.flags & 24u) && lane == 0) {  // (measurement: what hot words cost everybody -- four extra adds nobody waits for, on ONE line / on 64 lines)
+        unsigned long long *line = (a.flags & 8u) ? &a.dev->pad4[0] : reinterpret_cast<unsigned long long *>(a.dev->mirror + 60000u + (blockIdx.x & 63u) * 2u);
+        (void)atomicAdd(line, 1ull), (void)atomicAdd(line + 1, 1ull), (void)atomicAdd(line + 2, 1ull), (void)atomicAdd(line + 3, 1ull);
+    }
+    if (finish) {
+        const uint32_t b_n = c, nq_n = sl[12];
+        const bool claimer = sl[20] != 0u;
+        if (!claimer && c < sl[17] && !(a.flags & 64u)) bundle();  // (in flight together with the result stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every result store of the finished query has been acknowledged by memory
+        if (lane == 0 && (a.flags & 1u)) {  // (measurement: the old way -- everybody waits for its add to come back, the last one reports)
+            const u64 add = 1ull + (was_short ? (1ull << 32) : 0ull);
+            const u64 d = atomicAdd(&a.cells[b_n].done_short, add) + add;
+            if ((uint32_t)d == nq_n) {
+                RoarStreamDone *dn = a.done + (b_n & a.ring_mask);
+                __hip_atomic_store(&dn->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sys_store32(&dn->nshort, (uint32_t)(d >> 32));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sys_store32(&dn->seq1_done, b_n + 1u);
+            }
+        } else if (lane == 0) {
+            (void)atomicAdd(&a.cells[b_n].done_short, 1ull + (was_short ? (1ull << 32) : 0ull));
+            if (claimer) {  // this workgroup took the batch's last query: it reports the batch once every query of it has been counted
+                unsigned long long d;
+                const unsigned long long spin0 = (unsigned long long)wall_clock64();
                 for (;;) {
-                    const unsigned long long tt = __hip_atomic_load(&a.dev->tail_time, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    t = (uint32_t)tt & 0xFFFFFFu;
-                    if (t > want) break;
-                    if ((tt >> 24) != 0 && ((stream_clock40() - (tt >> 24)) & 0xFFFFFFFFFFull) <= STREAM_TAIL_LOOK_TICKS) break;
-                    if (dev_load32(&a.dev->checking) == 0u && atomicCAS(&a.dev->checking, 0u, 1u) == 0u) {
-                        const uint32_t h = sys_load32(&a.ctl->tail);  // (one workgroup at a time: the copy is simply replaced, the host's tail only grows)
-                        (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)h);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        (void)atomicExch(&a.dev->checking, 0u);
-                        t = h > t ? h : t;
+                    d = atomicAdd(&a.cells[b_n].done_short, 0ull);  // (an atomic like the adds it waits for, not a LOAD of their line: RoarStreamDev::state)
+                    if ((uint32_t)d >= nq_n) break;
+                    if ((unsigned long long)wall_clock64() - spin0 > STREAM_SPIN_LIMIT_TICKS) {
+                        sys_store32(&a.ctl->error, 2u);
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(32);
+                    __builtin_amdgcn_s_sleep(64);
                 }
+                RoarStreamDone *dn = a.done + (b_n & a.ring_mask);
+                __hip_atomic_store(&dn->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sys_store32(&dn->nshort, (uint32_t)(d >> 32));
+                sys_store32(&a.ctl->exited, (uint32_t)__hip_atomic_load(&a.dev->started_exited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (who has left by now)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the record's fields before its seq1_done; every result store of the batch
+                if ((uint32_t)d >= nq_n) sys_store32(&dn->seq1_done, b_n + 1u);  // was acknowledged before its workgroup counted the query)
             }
-            t = uni(t);
-            if (want >= t) {
-                // Nothing left.  Leave -- unless this is the last workgroup alive: that one tells the host how many have left and then
-                // looks at the host's tail itself (the host publishes a batch and THEN reads `exited` to decide whether workgroups
-                // must be started for it: one of the two sees the other's write; roar_search_stream_wait also starts workgroups when
-                // it finds a batch pending and too few alive: a lost race costs time, never a batch).  The host's count of who is
-                // alive is refreshed by every 64th workgroup to leave (a posted write each), by the last one, and with every batch.
-                uint32_t again = t;
-                if (lane == 0) {
-                    const unsigned long long se = atomicAdd(&a.dev->started_exited, 1ull) + 1ull;
-                    const uint32_t ex = (uint32_t)se, started = (uint32_t)(se >> 32);
-                    if (ex >= started) {
-                        sys_store32(&a.ctl->exited, ex);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the count is on its way before the tail is sampled)
-                        again = sys_load32(&a.ctl->tail);
-                        if (again > t) {
-                            (void)atomicExch(&a.dev->tail_time, (stream_clock40() << 24) | (unsigned long long)again);
-                            (void)atomicAdd(&a.dev->started_exited, ~0ull);  // (back in: one fewer has left)
-                        }
-                    } else if ((ex & 63u) == 0u) {
-                        sys_store32(&a.ctl->exited, ex);
-                    }
-                }
-                again = uni(again);
-                if (want >= again) return false;
-                t = again;
-            }
-            if (lane == 0) sl[17] = t;
-            wave_sync();
         }
-        uint32_t idx = 0;
-        if (lane == 0) idx = atomicAdd(&a.cells[want].next, 1u);
-        idx = uni(idx);
-        if (idx != 0xFFFFFFFFu && sl[18] != want + 1u) {  // this workgroup's copy is another batch's: the slot from the device's mirror, fetched from the host by ONE workgroup
-            uint32_t st = 0;
-            if (lane == 0) {
-                st = dev_load32(&a.cells[want].state);
-                if (st == 0) st = atomicCAS(&a.cells[want].state, 0u, 1u);
+    }
+    for (;;) {
+        if (!have) {
+            if (c >= sl[17]) {  // past what this workgroup knows to be published
+                uint32_t t = 0;
+                if (lane == 0) t = stream_more(a, c);
+                t = uni(t);
+                if (t == 0u) return false;
+                if (lane == 0) sl[17] = t;
+                wave_sync();
             }
+            bundle();
+        }
+        have = false;
+        idx = uni(idx);
+        f = uni(f);
+        bool exhausted = false;
+        if (sl[18] != c + 1u) {  // the batch's slot: from the device's mirror (state 2), else fetched from the host by ONE workgroup
             st = uni(st);
-            RoarStreamSlot *const mir = a.dev->mirror + (want & a.ring_mask);
-            if (st == 0) {  // elected: the slot over PCIe (64 bytes), seqlock-checked, then into the mirror
-                const RoarStreamSlot *slot = a.slots + (want & a.ring_mask);
-                uint32_t w = 0;
-                if (lane < 16) w = sys_load32(reinterpret_cast<const uint32_t *>(slot) + lane);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the second look at seq1 must be sampled after the fields)
-                uint32_t seq_again = 0;
-                if (lane == 0) seq_again = sys_load32(&slot->seq1);
-                const bool ok = lane_u32(w, 15) == want + 1u && uni(seq_again) == want + 1u;
-                if (ok && lane < 16) dev_store32(reinterpret_cast<uint32_t *>(mir) + lane, w);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) (void)atomicExch(&a.cells[want].state, ok ? 2u : 3u);
-                st = ok ? 2u : 3u;
-            } else {
-                while (st == 1u) {  // (the elected workgroup is two PCIe round trips away from done)
-                    __builtin_amdgcn_s_sleep(32);
-                    if (lane == 0) st = dev_load32(&a.cells[want].state);
+            // (the bundle read the state word and the mirror entry side by side: "there" may have been sampled after the entry was written
+            // and the entry before -- an entry is taken only if it names its batch in its last word, else it is read again, now behind the state)
+            bool got = st == 2u && lane_u32(w, 15) == c + 1u;
+            if (st == 0u) {  // nobody has fetched it: this workgroup does, if it wins the election
+                uint32_t w2 = 0;
+                st = stream_fetch(a, lane, c, w2);
+                if (st == 2u) w = w2, got = true;
+                else if (st == 0u) {
+                    if (lane == 0) st = dev_load32(&a.dev->state[c]);
                     st = uni(st);
                 }
             }
-            bool ok = st == 2u;
-            if (ok) {  // (a mirror entry is rewritten only for the batch `ring` numbers later, i.e. after this one is complete: checked)
-                uint32_t w = 0;
-                if (lane < 16) w = dev_load32(reinterpret_cast<const uint32_t *>(mir) + lane);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                uint32_t seq_again = 0;
-                if (lane == 0) seq_again = dev_load32(&mir->seq1);
-                ok = lane_u32(w, 15) == want + 1u && uni(seq_again) == want + 1u;
-                if (lane < 16) sl[lane] = w;
+            if (st == 1u) {  // somebody else is fetching it: two PCIe round trips away from done
+                const unsigned long long spin0 = (unsigned long long)wall_clock64();
+                while (st == 1u) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (lane == 0) {
+                        st = dev_load32(&a.dev->state[c]);
+                        if (st == 1u && (unsigned long long)wall_clock64() - spin0 > STREAM_SPIN_LIMIT_TICKS) {
+                            sys_store32(&a.ctl->error, 1u);
+                            st = 3u;
+                        }
+                    }
+                    st = uni(st);
+                }
             }
-            if (lane == 0) sl[18] = ok ? want + 1u : 0u;
-            wave_sync();
-            if (!ok) {  // the slot already held a later batch: batch `want` was complete long ago
-                if (lane == 0) sl[16] = want + 1u;
+            if (st == 2u && !got) {  // there for good: read it (again)
+                if (lane < 16) w = dev_load32(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane);
+                got = lane_u32(w, 15) == c + 1u;
+            }
+            if (got) {
+                if (lane < 16) sl[lane] = w;
+                if (lane == 0) sl[18] = c + 1u;
                 wave_sync();
-                continue;
+            } else {
+                exhausted = true;  // (3: the host's slot already held a later batch -- this one was complete long ago)
             }
         }
-        if (idx >= sl[12]) {
-            // The batch has no query left to hand out: on to the first batch that may have one -- the frontier the others have
-            // reached, not simply the next one (with 1 250-query batches the chip's workgroups span two or three batches, and walking
-            // them one by one is as many futile adds on hot words per dequeue)
-            if (lane == 0) {
-                const uint32_t f = dev_load32(&a.dev->frontier);
-                sl[16] = f > want + 1u ? f : want + 1u;
-            }
+        if (exhausted || idx >= sl[12]) {
+            // nothing left in this batch: on to the first batch that may have something -- the frontier the others have reached, not
+            // simply the next one (with 1 250-query batches the chip's workgroups span two or three batches)
+            c = f > c + 1u ? f : c + 1u;
+            if (lane == 0) sl[16] = c;
             wave_sync();
             continue;
         }
-        if (idx == 0 && lane == 0)
-            __hip_atomic_store(&a.done[want & a.ring_mask].t_first, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (idx + 1u == sl[12] && lane == 0) {  // the batch's last query: nothing left in it for anybody else
-            (void)atomicMax(&a.dev->frontier, want + 1u);
-            sys_store32(&a.done[want & a.ring_mask].seq1_claimed, want + 1u);
+        // Whoever takes a batch's second / third query fetches the slot of the next / next but one batch, if it is published and nobody
+        // has: every workgroup that finishes a query needs one from the FRONTIER batch, and while that batch's slot is two PCIe round
+        // trips away nothing starts anywhere (measured: 1 250-query batches handed out 9 % slower than 10 000-query ones; this fetch
+        // happens a batch or two ahead instead, off everybody's path but its own)
+        if ((idx == 1u || idx == 2u) && c + idx < sl[17] && !(a.flags & 2u)) {
+            uint32_t stn = 1u;
+            if (lane == 0) stn = dev_load32(&a.dev->state[c + idx]);
+            if (uni(stn) == 0u) {
+                uint32_t w2 = 0;
+                (void)stream_fetch(a, lane, c + idx, w2);
+            }
+        }
+        if (lane == 0) {
+            sl[20] = (idx + 1u == sl[12]) ? 1u : 0u;
+            if (idx == 0 && !(a.flags & 4u))
+                __hip_atomic_store(&a.done[c & a.ring_mask].t_first, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (idx + 1u == sl[12]) {  // the batch's last query: nothing left in it for anybody else
+                (void)atomicMax(&a.dev->frontier, c + 1u);
+                if (!(a.flags & 4u)) sys_store32(&a.done[c & a.ring_mask].seq1_claimed, c + 1u);
+            }
         }
         q = idx;
         return true;
-    }
-}
-
-// The query is done and its results are stored (write-through): count it; the workgroup that finishes a batch's last query reports
-// the batch to the host.
-__device__ __forceinline__ void stream_finish(int lane, bool was_short) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every result store of this query has been acknowledged by memory
-    if (lane == 0) {
-        const StreamArgs a = stream_args();
-        const uint32_t want = a.sl[16];
-        const u64 add = 1ull + (was_short ? (1ull << 32) : 0ull);
-        const u64 now = atomicAdd(&a.cells[want].done_short, add) + add;
-        if ((uint32_t)now == a.sl[12]) {
-            RoarStreamDone *d = a.done + (want & a.ring_mask);
-            __hip_atomic_store(&d->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            sys_store32(&d->nshort, (uint32_t)(now >> 32));
-            sys_store32(&a.ctl->exited, (uint32_t)__hip_atomic_load(&a.dev->started_exited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (who has left by now)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the record's fields before its seq1_done; every result store of the batch
-            sys_store32(&d->seq1_done, want + 1u);            //  was acknowledged before its workgroup counted the query)
-        }
     }
 }
 
@@ -818,7 +908,7 @@ __device__ __forceinline__ void lds_barrier() {
 // PROT: the instantiation whose forgetful tag table keeps the tags of pool members (roar_wave.h TagProtect; LDS pool, one wave per query).
 // Its own instantiation for the same reason: the policy's code costs a launch that does not use it 2 % (SIFT shape, L_pq = 170).
 // SRC: where the queries come from -- 0 the launch's own batch (p.queries, p.nq); 1 the same while a host thread is still packing the
-// rows (waits on p.ready; pageable host query blocks); 2 the batch-stream form: a ring of submitted batches (stream_take).
+// rows (waits on p.ready; pageable host query blocks); 2 the batch-stream form: a ring of submitted batches (stream_next).
 template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, int SRC = 0, bool STATS = false, bool PROT = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr bool GATED = SRC == 1, STREAM = SRC == 2;
@@ -871,17 +961,26 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     if constexpr (STREAM) {
         if (lane == 0) {
             const StreamArgs a = stream_args();
-            a.sl[16] = p.s_start, a.sl[17] = p.s_tail, a.sl[18] = 0u;
+            a.sl[16] = p.s_start, a.sl[17] = p.s_tail, a.sl[18] = 0u, a.sl[20] = 0u;
             (void)atomicAdd(&a.dev->started_exited, 1ull << 32);
             // (what this launch was told at its start, sl[17], is not shared: the device's copy of the host's tail is written by looks at the host only)
         }
         wave_sync();
     }
 
+    [[maybe_unused]] bool s_fin = false, s_short = false;  // (batch-stream form: a finished query waits to be counted, with the next take)
     for (;;) {
         uint32_t q = 0;
         if constexpr (STREAM) {
-            if (!stream_take(lane, q)) return;  // (signed off in RoarStreamCtl::exited; the launch cell is not used)
+            const long long tk0 = wall_clock64();
+            const bool more = stream_next(lane, s_fin, s_short, q);
+            if (lane == 0) {  // (what the dequeues cost, all workgroups together: two adds nobody waits for)
+                const StreamArgs a = stream_args();
+                (void)atomicAdd(&a.dev->take_ticks, (unsigned long long)(wall_clock64() - tk0));
+                (void)atomicAdd(&a.dev->take_calls, 1ull);
+                a.sl[22] = (uint32_t)wall_clock64();
+            }
+            if (!more) return;  // (counted out in RoarStreamDev; the launch cell is not used)
         } else if constexpr (W == 1) {
             if (lane == 0) q = atomicAdd(p.counter, 1u);
             q = uni(q);
@@ -1017,6 +1116,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             wave_sync();
         }
 
+        if constexpr (STREAM) if (lane == 0) { const StreamArgs a_ = stream_args(); a_.sl[23] = (uint32_t)wall_clock64(); (void)atomicAdd(&a_.dev->pad4[1], (unsigned long long)(a_.sl[23] - a_.sl[22])); }  // (measurement: set-up)
         for (;;) {
             uint32_t m = 0;
             bool done = false;
@@ -1263,6 +1363,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
         }
 
+        if constexpr (STREAM) if (lane == 0) { const StreamArgs a_ = stream_args(); (void)atomicAdd(&a_.dev->pad4[2], (unsigned long long)((uint32_t)wall_clock64() - a_.sl[23])); }  // (measurement: hop loop)
         // results (:2408-2418); a short pool is reported, not thrown
         if (wid == 0) {
             // The output pointers are used here only, once per query: they are read from the kernel-argument segment
@@ -1325,7 +1426,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     o[13] = o[14] = o[15] = 0;
                 }
             }
-            if constexpr (STREAM) stream_finish(lane, psize < p.k);
+            if constexpr (STREAM) {
+                s_fin = true, s_short = psize < p.k;  // (counted by stream_next, while the stores above are in flight)
+                if (lane == 0) {
+                    const StreamArgs a = stream_args();
+                    (void)atomicAdd(&a.dev->busy_ticks, (unsigned long long)((uint32_t)wall_clock64() - a.sl[22]));
+                }
+            }
         }
         block_sync();
     }

@@ -77,7 +77,7 @@ constexpr double WAIT_TIMEOUT_S = 60.0;
 
 size_t pin_bytes(const roar_stream *s) { return sizeof(RoarStreamCtl) + (size_t)s->ring * (sizeof(RoarStreamSlot) + sizeof(RoarStreamDone)); }
 
-size_t dev_bytes(const roar_stream *s) { return sizeof(RoarStreamDev) + (size_t)s->ring * sizeof(RoarStreamSlot); }
+size_t dev_bytes(const roar_stream *s) { return sizeof(RoarStreamDev) + (size_t)s->cap * sizeof(RoarStreamSlot); }
 
 uint32_t alive(roar_stream *s) {
     const uint32_t ex = *reinterpret_cast<volatile uint32_t *>(&s->ctl->exited);
@@ -194,6 +194,10 @@ int wait_for(roar_stream *s, std::unique_lock<std::mutex> &lk, Pred pred, const 
         poll(s);
         if (pred()) return ROAR_OK;
         if (s->broken) return fail(ROAR_ERR_DEVICE, "search stream: an earlier call failed; close the stream");
+        if (const uint32_t code = *reinterpret_cast<volatile uint32_t *>(&s->ctl->error)) {
+            s->broken = true;
+            return fail(ROAR_ERR_DEVICE, "search stream: a workgroup gave up waiting for another one (code %u: 1 slot fetch, 2 batch count, 3 tail look)", code);
+        }
         if ((++spins & 0x3FFu) == 0) {
             if (s->pending_q) {
                 int e = top_up(s, true);
@@ -324,6 +328,7 @@ int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t
         p.s_cells = s->cells;
         p.s_dev = s->dev;
         p.s_ring = s->ring;
+        p.s_flags = getenv("ROAR_STREAM_FLAGS") ? (uint32_t)atoi(getenv("ROAR_STREAM_FLAGS")) : 0u;
         p.nq = 0;
         s->R = std::max<uint32_t>(s->plan.grid, 1);
         s->planned = true;
@@ -431,6 +436,15 @@ int roar_search_stream_info(roar_stream *s, const char *key, int64_t *value) {
     else if (k == "tag_protect") *value = s->planned ? s->plan.sel.protect : 0;
     else if (k == "register_pool") *value = s->planned ? s->plan.sel.regpool : 0;
     else if (k == "wall_clock_khz") *value = s->wall_khz;
+    else if (k == "setup_ns_total" || k == "hops_ns_total") {  // (measurement)
+        unsigned long long v[3] = {0, 0, 0};
+        if (s->dev && hipMemcpy(v, &s->dev->pad4[0], sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(ROAR_ERR_DEVICE, "search stream: cannot read the counters");
+        *value = (int64_t)((double)(k == "setup_ns_total" ? v[1] : v[2]) * 1.0e6 / (double)s->wall_khz);
+    } else if (k == "take_ns_total" || k == "take_calls" || k == "busy_ns_total") {  // what the workgroups' dequeues / searches cost (device clock, all workgroups together, this epoch)
+        unsigned long long v[3] = {0, 0, 0};
+        if (s->dev && hipMemcpy(v, &s->dev->take_ticks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(ROAR_ERR_DEVICE, "search stream: cannot read the counters");
+        *value = k == "take_calls" ? (int64_t)v[1] : (int64_t)((double)(k == "busy_ns_total" ? v[2] : v[0]) * 1.0e6 / (double)s->wall_khz);
+    }
     else return fail(ROAR_ERR_ARG, "Invalid parameter name.");
     return ROAR_OK;
 }

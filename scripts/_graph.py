@@ -6,7 +6,7 @@ import torch
 from mysteryann_amd import index as mi, synth
 
 
-def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="/tmp/r3_graph2.index", say=print, stage2=-1, stage2_L=600):
+def t2i_index(n=10_000_000, nq=10_000, builder="reference", ref_learn=0, cache="/tmp/roar_graph.index", say=print, stage2=-1, stage2_L=600):
     """bench.py's default index (exact lists of as many training queries as base points, bench.build_reference_graph) unless told
     otherwise (ref_learn < n: round 3's two-stage lists)."""
     d = 200

@@ -1,5 +1,5 @@
-timeout 600 python -m pytest tests/test_search_stream.py -x -q 2>&1 | tail -15 > gpurun_out/r5_stream_tests.log
-timeout 1500 python bench.py --steps 20 --warmup 3 --no-traffic --no-cpu-baseline --no-host-path > gpurun_out/r5_bench_a.json 2> gpurun_out/r5_bench_a.err
+timeout 300 python -m pytest tests/test_search_stream.py -x -q 2>&1 | tail -15 > gpurun_out/r5_stream_tests.log
+timeout 600 python bench.py --steps 20 --warmup 3 --no-traffic --no-cpu-baseline --no-host-path > gpurun_out/r5_bench_a.json 2> gpurun_out/r5_bench_a.err
 tail -3 gpurun_out/r5_stream_tests.log; grep "batch stream\|timeline" gpurun_out/r5_bench_a.err
 python3 -c "
 import json

@@ -43,6 +43,23 @@ def test_facade_header_compiles_without_device(tmp_path):
     assert os.system(str(exe)) == 0
 
 
+def test_harness_include_block_of_the_reference_resolves_against_the_forwarding_headers(tmp_path, built_lib):
+    """include/compat/: a harness whose quoted includes are spelled as the reference's (tests/test_search_roargraph.cpp:14-18 --
+    efanna2e/{distance,neighbor,parameters,util}.h, index_bipartite.h) builds with -I include/compat alone and links against the
+    library; run without arguments it touches no GPU."""
+    src = os.path.join(ROOT, "tests", "compat", "harness_include_block.cpp")
+    text = open(src).read()
+    for h in ("efanna2e/distance.h", "efanna2e/neighbor.h", "efanna2e/parameters.h", "efanna2e/util.h", "index_bipartite.h"):
+        assert f'#include "{h}"' in text
+        assert os.path.exists(os.path.join(ROOT, "include", "compat", h))
+    exe = tmp_path / "compat"
+    csrc = os.path.join(ROOT, "mysteryann_amd", "csrc")
+    assert os.system(f"g++ -std=c++17 -fopenmp -Wall -I{ROOT}/include/compat {src} -o {exe} -L{csrc} -lroargraph_amd "
+                     f"-Wl,-rpath,{csrc}") == 0
+    assert os.system(f"{exe} > {tmp_path}/out.txt") == 0
+    assert "compat headers ok" in open(tmp_path / "out.txt").read()
+
+
 def test_facade_loader_blocks_are_released_like_the_references(tmp_path, golden_dir):
     """A ported harness releases what load_data / data_align return with delete[] / free
     (tests/test_search_roargraph.cpp:242-247; the reference allocates them with memalign, util.h:64,196): the facade's

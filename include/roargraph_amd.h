@@ -213,7 +213,8 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
  * searches on the same device share the chip with the stream's workgroups.
  * info keys: "launches" (kernel launches so far), "workgroups_launched", "workgroups_alive", "resident_capacity", "heals" (times
  * wait() found a batch pending and no workgroup alive), "epochs", "batches_submitted", "batches_completed", "ring", "lds_bytes",
- * "screen", "vis_entries", "tag_protect", "register_pool", "wall_clock_khz". */
+ * "screen", "vis_entries", "tag_protect", "register_pool", "wall_clock_khz"; "take_calls" / "take_ns_total" / "busy_ns_total": calls of
+ * the kernel's dequeue, device time all workgroups together spent in it / in the searches between (this epoch; one device read each). */
 typedef struct roar_stream roar_stream;
 int roar_search_stream_open(roar_index *idx, uint32_t k, uint32_t L_pq, roar_stream **out);
 int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t *ids_dev,

@@ -146,8 +146,6 @@ struct RoarSearchParams {
     uint32_t s_ring;
     uint32_t s_start;
     uint32_t s_tail;  // batches published when this launch was made
-    uint32_t s_flags; // measurement switches (environment ROAR_STREAM_FLAGS): 1 the last finisher reports a batch (an add everybody waits for) instead of
-                      // the taker of its last query polling; 2 no fetching of slots ahead; 4 no t_first / claimed records
     uint32_t off_stream;
 };
 

@@ -625,7 +625,6 @@ struct StreamArgs {
     RoarStreamCell *cells;
     RoarStreamDev *dev;
     uint32_t ring_mask;
-    uint32_t flags;
     volatile uint32_t *sl;
 };
 __device__ __forceinline__ StreamArgs stream_args() {
@@ -639,7 +638,6 @@ __device__ __forceinline__ StreamArgs stream_args() {
     a.cells = *const_cast<RoarStreamCell *const volatile *>(&ka->s_cells);
     a.dev = *const_cast<RoarStreamDev *const volatile *>(&ka->s_dev);
     a.ring_mask = *const_cast<const uint32_t volatile *>(&ka->s_ring) - 1u;
-    a.flags = *const_cast<const uint32_t volatile *>(&ka->s_flags);
     a.sl = reinterpret_cast<volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_stream));
 #else
     a = StreamArgs{};  // (host pass of the compiler: never executed)
@@ -749,37 +747,17 @@ __device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_shor
         if (lane == 0) {
             idx = atomicAdd(&a.cells[c].next, 1u);
             f = dev_load32(&a.dev->frontier);
-            if (need) st = (a.flags & 128u) ? __builtin_nontemporal_load(&a.dev->state[c]) : dev_load32(&a.dev->state[c]);
+            if (need) st = dev_load32(&a.dev->state[c]);
         }
-        if (need && lane < 16)
-            w = (a.flags & 128u) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane)
-                                 : dev_load32(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane);
+        if (need && lane < 16) w = dev_load32(reinterpret_cast<const uint32_t *>(a.dev->mirror + c) + lane);
         have = true;
     };
-    if (finish && (a.flags & 32u)) {  // (measurement: every take goes the long way -- the slot is read from the mirror again)
-        if (lane == 0) sl[18] = 0u;
-        wave_sync();
-    }
-    if (finish && (a.flags & 24u) && lane == 0) {  // (measurement: what hot words cost everybody -- four extra adds nobody waits for, on ONE line / on 64 lines)
-        unsigned long long *line = (a.flags & 8u) ? &a.dev->pad4[0] : reinterpret_cast<unsigned long long *>(a.dev->mirror + 60000u + (blockIdx.x & 63u) * 2u);
-        (void)atomicAdd(line, 1ull), (void)atomicAdd(line + 1, 1ull), (void)atomicAdd(line + 2, 1ull), (void)atomicAdd(line + 3, 1ull);
-    }
     if (finish) {
         const uint32_t b_n = c, nq_n = sl[12];
         const bool claimer = sl[20] != 0u;
-        if (!claimer && c < sl[17] && !(a.flags & 64u)) bundle();  // (in flight together with the result stores)
+        if (!claimer && c < sl[17]) bundle();  // (in flight together with the result stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every result store of the finished query has been acknowledged by memory
-        if (lane == 0 && (a.flags & 1u)) {  // (measurement: the old way -- everybody waits for its add to come back, the last one reports)
-            const u64 add = 1ull + (was_short ? (1ull << 32) : 0ull);
-            const u64 d = atomicAdd(&a.cells[b_n].done_short, add) + add;
-            if ((uint32_t)d == nq_n) {
-                RoarStreamDone *dn = a.done + (b_n & a.ring_mask);
-                __hip_atomic_store(&dn->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                sys_store32(&dn->nshort, (uint32_t)(d >> 32));
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                sys_store32(&dn->seq1_done, b_n + 1u);
-            }
-        } else if (lane == 0) {
+        if (lane == 0) {
             (void)atomicAdd(&a.cells[b_n].done_short, 1ull + (was_short ? (1ull << 32) : 0ull));
             if (claimer) {  // this workgroup took the batch's last query: it reports the batch once every query of it has been counted
                 unsigned long long d;
@@ -796,7 +774,7 @@ __device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_shor
                 RoarStreamDone *dn = a.done + (b_n & a.ring_mask);
                 __hip_atomic_store(&dn->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 sys_store32(&dn->nshort, (uint32_t)(d >> 32));
-                sys_store32(&a.ctl->exited, (uint32_t)__hip_atomic_load(&a.dev->started_exited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (who has left by now)
+                sys_store32(&a.ctl->exited, (uint32_t)atomicAdd(&a.dev->started_exited, 0ull));  // (who has left by now; an add of zero, not a load: RoarStreamDev::state)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the record's fields before its seq1_done; every result store of the batch
                 if ((uint32_t)d >= nq_n) sys_store32(&dn->seq1_done, b_n + 1u);  // was acknowledged before its workgroup counted the query)
             }
@@ -870,7 +848,7 @@ __device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_shor
         // has: every workgroup that finishes a query needs one from the FRONTIER batch, and while that batch's slot is two PCIe round
         // trips away nothing starts anywhere (measured: 1 250-query batches handed out 9 % slower than 10 000-query ones; this fetch
         // happens a batch or two ahead instead, off everybody's path but its own)
-        if ((idx == 1u || idx == 2u) && c + idx < sl[17] && !(a.flags & 2u)) {
+        if ((idx == 1u || idx == 2u) && c + idx < sl[17]) {
             uint32_t stn = 1u;
             if (lane == 0) stn = dev_load32(&a.dev->state[c + idx]);
             if (uni(stn) == 0u) {
@@ -880,11 +858,11 @@ __device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_shor
         }
         if (lane == 0) {
             sl[20] = (idx + 1u == sl[12]) ? 1u : 0u;
-            if (idx == 0 && !(a.flags & 4u))
+            if (idx == 0)
                 __hip_atomic_store(&a.done[c & a.ring_mask].t_first, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (idx + 1u == sl[12]) {  // the batch's last query: nothing left in it for anybody else
                 (void)atomicMax(&a.dev->frontier, c + 1u);
-                if (!(a.flags & 4u)) sys_store32(&a.done[c & a.ring_mask].seq1_claimed, c + 1u);
+                sys_store32(&a.done[c & a.ring_mask].seq1_claimed, c + 1u);
             }
         }
         q = idx;
@@ -1116,7 +1094,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             wave_sync();
         }
 
-        if constexpr (STREAM) if (lane == 0) { const StreamArgs a_ = stream_args(); a_.sl[23] = (uint32_t)wall_clock64(); (void)atomicAdd(&a_.dev->pad4[1], (unsigned long long)(a_.sl[23] - a_.sl[22])); }  // (measurement: set-up)
         for (;;) {
             uint32_t m = 0;
             bool done = false;
@@ -1363,7 +1340,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
         }
 
-        if constexpr (STREAM) if (lane == 0) { const StreamArgs a_ = stream_args(); (void)atomicAdd(&a_.dev->pad4[2], (unsigned long long)((uint32_t)wall_clock64() - a_.sl[23])); }  // (measurement: hop loop)
         // results (:2408-2418); a short pool is reported, not thrown
         if (wid == 0) {
             // The output pointers are used here only, once per query: they are read from the kernel-argument segment

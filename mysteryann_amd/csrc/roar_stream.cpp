@@ -328,7 +328,6 @@ int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t
         p.s_cells = s->cells;
         p.s_dev = s->dev;
         p.s_ring = s->ring;
-        p.s_flags = getenv("ROAR_STREAM_FLAGS") ? (uint32_t)atoi(getenv("ROAR_STREAM_FLAGS")) : 0u;
         p.nq = 0;
         s->R = std::max<uint32_t>(s->plan.grid, 1);
         s->planned = true;
@@ -436,11 +435,7 @@ int roar_search_stream_info(roar_stream *s, const char *key, int64_t *value) {
     else if (k == "tag_protect") *value = s->planned ? s->plan.sel.protect : 0;
     else if (k == "register_pool") *value = s->planned ? s->plan.sel.regpool : 0;
     else if (k == "wall_clock_khz") *value = s->wall_khz;
-    else if (k == "setup_ns_total" || k == "hops_ns_total") {  // (measurement)
-        unsigned long long v[3] = {0, 0, 0};
-        if (s->dev && hipMemcpy(v, &s->dev->pad4[0], sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(ROAR_ERR_DEVICE, "search stream: cannot read the counters");
-        *value = (int64_t)((double)(k == "setup_ns_total" ? v[1] : v[2]) * 1.0e6 / (double)s->wall_khz);
-    } else if (k == "take_ns_total" || k == "take_calls" || k == "busy_ns_total") {  // what the workgroups' dequeues / searches cost (device clock, all workgroups together, this epoch)
+    else if (k == "take_ns_total" || k == "take_calls" || k == "busy_ns_total") {  // what the workgroups' dequeues / searches cost (device clock, all workgroups together, this epoch)
         unsigned long long v[3] = {0, 0, 0};
         if (s->dev && hipMemcpy(v, &s->dev->take_ticks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(ROAR_ERR_DEVICE, "search stream: cannot read the counters");
         *value = k == "take_calls" ? (int64_t)v[1] : (int64_t)((double)(k == "busy_ns_total" ? v[2] : v[0]) * 1.0e6 / (double)s->wall_khz);

@@ -53,7 +53,6 @@ def run(bs, total, mode):
         torch.cuda.synchronize()
         l0 = st.info("launches")
         tn0, tc0, tb0 = st.info("take_ns_total"), st.info("take_calls"), st.info("busy_ns_total")
-        ts0, th0 = st.info("setup_ns_total"), st.info("hops_ns_total")
         t0 = time.perf_counter()
         lead = None
         if os.environ.get("LEAD"):  # one 10 000-query batch in front: the whole stream is then served by ONE launch of workgroups
@@ -70,7 +69,6 @@ def run(bs, total, mode):
         wall = time.perf_counter() - t0
         tt = [st.times(t) for t in tk]
         tn1, tc1, tb1 = st.info("take_ns_total"), st.info("take_calls"), st.info("busy_ns_total")
-        ts1, th1 = st.info("setup_ns_total"), st.info("hops_ns_total")
         span = (max(b for _, b in tt) - min(a for a, _ in tt)) * 1e-3
         k0 = min(3, steps - 2)
         steady = (tt[-1][0] - tt[k0][0]) * 1e-3 / max(1, steps - 1 - k0) if steps > k0 + 1 else float("nan")
@@ -78,16 +76,15 @@ def run(bs, total, mode):
         print(f"bs={bs:6d} total={total:7d} rows={mode:5s}: wall {wall * 1e6:8.0f} us = {wall * 1e3 / steps:.4f} ms/step = {total / wall / 1e6:.2f} M QPS | device span {span:8.0f} us | "
               f"steady hand-out {steady:7.1f} us/batch = {bs / steady:.2f} M QPS | last batch taken..done {drain:.0f} us | submits {t_sub * 1e6:.0f} us, "
               f"launches {st.info('launches') - l0}, alive after submits {alive_mid}, heals {st.info('heals')}, "
-              f"dequeue {(tn1 - tn0) / max(1, tc1 - tc0) / 1e3:.1f} us per call over {tc1 - tc0} calls, search {(tb1 - tb0) / total / 1e3:.1f} us per query (set-up {(ts1 - ts0) / total / 1e3:.1f}, hops {(th1 - th0) / total / 1e3:.1f}), "
+              f"dequeue {(tn1 - tn0) / max(1, tc1 - tc0) / 1e3:.1f} us per call over {tc1 - tc0} calls, search {(tb1 - tb0) / total / 1e3:.1f} us per query, "
               f"workgroup-time accounted {((tn1 - tn0) + (tb1 - tb0)) / 1e3 / 3072:.0f} us of span", flush=True)
     finally:
         st.close()
 
 
-for flags in os.environ.get("FLAGS", "0").split(","):
-    os.environ["ROAR_STREAM_FLAGS"] = flags
+if True:
     for mg in [int(x) for x in os.environ.get("MAXGRID", "0").split(",")]:
         idx.set_option("max_grid", mg)
-        print(f"# ROAR_STREAM_FLAGS={flags} max_grid={mg}", flush=True)
+        print(f"# L_pq={L} max_grid={mg}", flush=True)
         for bs in [int(x) for x in os.environ.get('BS', '10000,2500,1250').split(',')] * int(os.environ.get('REPEAT', '1')):
             run(bs, 200_000, os.environ.get("MODE", "share"))

@@ -283,7 +283,7 @@ int ensure_hub_rows(roar_index *idx) {
     return ROAR_OK;
 }
 
-// The screening copy (roar_search_v2.h, screen8_pass): + n x roar_screen8_stride(dim) bytes of HBM (256 at 200-d, 528 at 512-d), one
+// The screening copy (roar_search_v2.h, screen8_pass): + roar_screen8_bytes(dim, n) of HBM (256 per row at 200-d, 512 + 16 at 512-d), one
 // conversion pass.  Failure to make it is not an
 // error: the launch then scores every neighbour on the f32 rows, as without it.
 void ensure_screen(roar_index *idx) {
@@ -300,7 +300,7 @@ void ensure_screen(roar_index *idx) {
         idx->screen = nullptr;
         idx->screen_mu = nullptr;
     };
-    if (roar_dev_malloc((void **)&idx->screen, (size_t)idx->n * roar_screen8_stride(idx->dim_pad) + 256) != hipSuccess) return drop();
+    if (roar_dev_malloc((void **)&idx->screen, (size_t)roar_screen8_bytes(idx->dim_pad, idx->n) + 256) != hipSuccess) return drop();
     int rc = 0;
     if (idx->ip) {
         // Centred codes (roar_search_v2.h): the centre is the component-wise MEDIAN of a strided sample of (at most) 4 096 rows -- any

@@ -178,13 +178,21 @@ struct RoarDistParams {
     uint32_t off_ck, off_cid, off_q, lds_bytes;
 };
 
-// Bytes per row of the screening copy: dim / 16 chunks of 16 codes, then one 16-byte chunk holding the last dim % 16 (0 or 8)
-// codes, the scale and the bound.  Rows are packed when a packed row never touches more 128-byte lines than a row padded to whole
-// lines would (512-d: 528 bytes, always five lines), padded otherwise (200-d: 208 -> 256 bytes, two lines instead of two or three).
+// The screening copy.  A row of codes is dim / 16 chunks of 16 codes; its 16 bytes of floats (inner product: the last dim % 16 (0 or 8)
+// codes, the scale and the two bounds; L2: scale, lo, |x~|^2, bound) live
+//   * INSIDE the row where the codes do not fill whole 128-byte lines anyway (200-d: 208 -> 256 bytes, two lines instead of two or three),
+//   * in a packed array BEHIND the code rows (16 bytes per row, at byte n x stride of the copy) where they do (128-d, 512-d): round 4
+//     kept them in the row -- 528 bytes, always five lines for 4.1 lines of payload at 512-d; now four whole lines + one 16-byte
+//     read (eight rows' floats share a line, and hub rows' lines stay in L2).
+static inline constexpr bool roar_screen8_split(uint32_t dim) { return dim % 128u == 0u; }
 static inline constexpr uint32_t roar_screen8_stride(uint32_t dim) {
-    return (112u + (dim / 16u + 1u) * 16u + 127u) / 128u <= ((dim / 16u + 1u) * 16u + 127u) / 128u ? (dim / 16u + 1u) * 16u
+    return roar_screen8_split(dim) ? dim
+           : (112u + (dim / 16u + 1u) * 16u + 127u) / 128u <= ((dim / 16u + 1u) * 16u + 127u) / 128u ? (dim / 16u + 1u) * 16u
                                                                                                      : ((dim / 16u + 1u) * 16u + 127u) & ~127u;
 }
+// bytes a scored row asks the memory side for / bytes of the whole copy of n rows
+static inline constexpr uint32_t roar_screen8_row_bytes(uint32_t dim) { return roar_screen8_stride(dim) + (roar_screen8_split(dim) ? 16u : 0u); }
+static inline constexpr uint64_t roar_screen8_bytes(uint32_t dim, uint64_t n) { return n * (uint64_t)roar_screen8_row_bytes(dim); }
 // L2 form: allowance for the rounding of |x~|^2 - 2 x~.q + |q|^2 as the kernel evaluates it, in units of |x~|^2 + |q|^2
 static inline constexpr double roar_screen8_l2_rounding(uint32_t dim) {
     double y = (double)dim;
@@ -201,17 +209,17 @@ int roar_launch_distances(const RoarDistParams *p, int metric_ip, void *stream);
 int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint32_t *ids, const float *dists,
                            uint32_t *out_ids, float *out_dists, void *stream);
 // f32 rows of dim floats (dim % 8 == 0, dim <= 1024) at stride ld -> screening rows (see RoarSearchParams::screen);
-// out: n x roar_screen8_stride(dim) bytes
+// out: roar_screen8_bytes(dim, n) bytes (code rows, then -- roar_screen8_split -- the rows' floats)
 // l2 != 0: the L2 form of the row (dim % 16 == 0): dim codes u_i with x~_i = lo + s u_i, then s, lo, |x~|^2, bound
 // mu (inner-product form only; may be null): dim floats the codes are centred on
-int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream);
+int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream);  // out: roar_screen8_bytes(dim, n)
 int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
 // tests: the search's own screening passes over explicit (query, row) pairs, every row against its own threshold (roar_search_v2.h,
 // roar_screen_check_kernel); _1 = inner product, _0 = L2
 int roar_launch_screen_check_1(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
-                               const uint32_t *ids, float *chk, uint32_t m, void *stream);
+                               const uint32_t *ids, float *chk, uint32_t m, uint64_t n_rows, void *stream);
 int roar_launch_screen_check_0(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
-                               const uint32_t *ids, float *chk, uint32_t m, void *stream);
+                               const uint32_t *ids, float *chk, uint32_t m, uint64_t n_rows, void *stream);
 // Max resident workgroups per CU for the selected kernel at this LDS size.
 int roar_search_occupancy(const RoarKernelSel *sel, uint32_t dim, uint32_t lds_bytes, int *blocks_per_cu);
 #ifdef __cplusplus

@@ -414,7 +414,7 @@ __device__ __forceinline__ uint32_t bf16_up(float v) {  // v >= 0 or +inf: the s
 }
 
 __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
-                                                                uint32_t stride, const float *__restrict__ mu) {
+                                                                uint32_t stride, const float *__restrict__ mu, unsigned char *__restrict__ meta_out) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (v >= n) return;
@@ -471,6 +471,13 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
     // bound is about the real one (|fl(y) - y| <= 2^-24 |y|, |y| <= N + B)
     const float nrm = sc * __builtin_sqrtf(c2) * 1.0001f;
     const float bnd = 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 2.4e-7f * nrm;
+    if (meta_out) {  // (roar_screen8_split: the rows' floats are a packed array behind the code rows)
+        uint32_t *m32 = reinterpret_cast<uint32_t *>(meta_out + v * 16u);
+        if (lane < 2) m32[lane] = 0u;
+        if (lane == 2) m32[2] = __float_as_uint(anybad ? 0.f : sc);
+        if (lane == 3) m32[3] = anybad ? 0x7F80u : (bf16_up(bnd) | (bf16_up(nrm) << 16));
+        return;
+    }
     if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
     if (lane == 1) o32[meta + 1] = anybad ? 0x7F80u : (bf16_up(bnd) | (bf16_up(nrm) << 16));
     for (uint32_t w = nf4 + lane; w < stride / 4; w += 64)  // zeros between the codes and the meta words, and after them
@@ -482,7 +489,7 @@ __global__ void __launch_bounds__(256) roar_make_screen8_kernel(const float *__r
 // == 0), s, lo, |x~|^2, B with B >= |x - x~| + the distance between the x~ the kernel means (lo + s u in real arithmetic) and the
 // rounded one measured here.
 __global__ void __launch_bounds__(256) roar_make_screen8_l2_kernel(const float *__restrict__ base, u64 ld, uint32_t dim, u64 n, unsigned char *__restrict__ out,
-                                                                   uint32_t stride) {
+                                                                   uint32_t stride, unsigned char *__restrict__ meta_out) {
     const u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (v >= n) return;
@@ -551,12 +558,14 @@ __global__ void __launch_bounds__(256) roar_make_screen8_l2_kernel(const float *
     for (int j = 0; j < 4; ++j)
         if (64 * j + lane < nf4) o32[64 * j + lane] = anybad ? 0u : words[j];
     const uint32_t meta = (dim / 16u) * 4u;
-    if (lane == 0) o32[meta] = __float_as_uint(anybad ? 0.f : sc);
-    if (lane == 1) o32[meta + 1] = __float_as_uint(lo);
-    if (lane == 2) o32[meta + 2] = __float_as_uint(anybad ? 0.f : n2);
+    uint32_t *m32 = meta_out ? reinterpret_cast<uint32_t *>(meta_out + v * 16u) : o32 + meta;  // (roar_screen8_split: a packed array behind the code rows)
+    if (lane == 0) m32[0] = __float_as_uint(anybad ? 0.f : sc);
+    if (lane == 1) m32[1] = __float_as_uint(lo);
+    if (lane == 2) m32[2] = __float_as_uint(anybad ? 0.f : n2);
     if (lane == 3)
-        o32[meta + 3] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 2.5e-7f * __builtin_sqrtf(n2) * 1.0001f);
-    for (uint32_t w = meta + 4 + lane; w < stride / 4; w += 64) o32[w] = 0u;
+        m32[3] = __float_as_uint(anybad ? __builtin_inff() : 1.001f * sc * __builtin_sqrtf(e2) * 1.0001f + 2.5e-7f * __builtin_sqrtf(n2) * 1.0001f);
+    if (!meta_out)
+        for (uint32_t w = meta + 4 + lane; w < stride / 4; w += 64) o32[w] = 0u;
 }
 
 // local ids of a shard -> global ids (index-sharded configuration); "no result" stays "no result"
@@ -751,13 +760,14 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
 extern "C" int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream) {
     if (n == 0) return 0;
     if (dim % 8 || dim > 1024 || (l2 && dim % 16)) return (int)hipErrorInvalidValue;
+    unsigned char *const meta_out = roar_screen8_split(dim) ? out + (u64)n * roar_screen8_stride(dim) : nullptr;
     if (l2) {
         hipLaunchKernelGGL(roar_make_screen8_l2_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
-                           roar_screen8_stride(dim));
+                           roar_screen8_stride(dim), meta_out);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(roar_make_screen8_kernel, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, (u64)ld, dim, (u64)n, out,
-                       roar_screen8_stride(dim), mu);
+                       roar_screen8_stride(dim), mu, meta_out);
     return (int)hipGetLastError();
 }
 

@@ -128,18 +128,18 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // LDS-DMA with the address split the way the hardware takes it: uniform 64-bit base in scalar registers + 32-bit per-lane offset; the
 // LDS side is M0 (uniform base; the lanes' 16 / 4 bytes follow each other from there).  Every LDS-DMA of the pass kernel goes through
-// these four, so no M0 value of the compiler's is alive across them.
+// these four; each tells the compiler that it overwrites M0.
 __device__ __forceinline__ void dma_b128(const void *base, uint32_t off, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_b32(const void *base, uint32_t off, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_b128_at(const void *src, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_b32_at(const void *src, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128(uint32_t a, u32x4 &f) {

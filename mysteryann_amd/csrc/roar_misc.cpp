@@ -97,8 +97,8 @@ int roar_debug_screen_keeps(roar_index *idx, const float *queries, uint64_t nq, 
     HIP_TRY(hipMemcpy(q_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(i_dev, ids, (size_t)nq * m * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c_dev, thresholds, (size_t)nq * m * 4, hipMemcpyHostToDevice));
-    int rc = idx->ip ? roar_launch_screen_check_1(idx->screen, idx->screen_mu, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, nullptr)
-                     : roar_launch_screen_check_0(idx->screen, nullptr, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, nullptr);
+    int rc = idx->ip ? roar_launch_screen_check_1(idx->screen, idx->screen_mu, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, idx->n, nullptr)
+                     : roar_launch_screen_check_0(idx->screen, nullptr, idx->dim_pad, q_dev, idx->dim_pad, nq, i_dev, c_dev, m, idx->n, nullptr);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "screen check launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<float> verdict;
@@ -281,7 +281,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_knn_bf16") *value = idx->last_knn_bf16;
     else if (k == "last_knn_rerank_rows") *value = idx->last_knn_rerank_rows;
     else if (k == "calibrations") *value = (int64_t)idx->plan_cache.size();
-    else if (k == "screen_row_bytes") *value = roar_screen8_stride(idx->dim_pad);
+    else if (k == "screen_row_bytes") *value = roar_screen8_row_bytes(idx->dim_pad);
     else if (k == "launch_events_on") *value = idx->launch_events;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;

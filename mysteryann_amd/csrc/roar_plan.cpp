@@ -368,7 +368,10 @@ uint64_t plan_key(const roar_index *idx, uint64_t nq, uint32_t L) {
     // makes: uncapped) the calibration of that band.  (Timed alone under its cap, a third of the chip, every table looks the same:
     // the first build picked 16 384 tags for the capped launches of bench.py's timed loop and halved its rate.)
     const uint32_t band = idx->max_grid > 0 ? 7u : nqband;
-    return (uint64_t)lband | ((uint64_t)band << 8) | ((uint64_t)(idx->waves_per_cu & 0xFF) << 20);
+    // ... and by WHICH choices were free when the entry was measured: what is measured with an option fixed (screen forced on, the visited
+    // form given, a table size given) is conditional on it and says nothing about the launch with that option back on AUTO
+    const uint64_t fixed = (uint64_t)(idx->screen_mode & 3) | ((uint64_t)(idx->visited_mode & 3) << 2) | ((uint64_t)(idx->vis_entries & 0xFFFFF) << 4);
+    return (uint64_t)lband | ((uint64_t)band << 8) | ((uint64_t)(idx->waves_per_cu & 0xFF) << 20) | (fixed << 28);
 }
 
 const roar_index::Calibration *find_calibration(const roar_index *idx, uint64_t key) {
@@ -404,6 +407,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     idx->max_grid = 0;  // (candidates are timed on the whole chip: see plan_key)
     uint32_t runs = 0;
     int hard_error = ROAR_OK;
+    bool used_lists = false;  // some candidate used the per-workgroup lists in HBM: later launches of other streams are ordered behind it
     // one candidate: planned for the sample, launched, timed; short launches twice (the faster counts: the first launch of a
     // kernel form also pays its code-object load).  -> ms, or a negative value if the candidate cannot run here
     auto time_pick = [&](const PlanPick &pk, uint32_t *entries_used, int *mode_used, int *screen_used) -> float {
@@ -424,6 +428,12 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
             pl.p.qstride = qstride;
             pl.p.out_ids = sc_ids;
             pl.p.out_dists = sc_d;
+            // a candidate that uses the per-workgroup lists in HBM (HBM tags, spill lists) must not run beside a launch of another stream
+            // that still uses them: the ordering search_device applies (roar_launch.cpp)
+            if (pl.p.tags != nullptr || idx->last_used_tags) {
+                if (idx->ev_valid && idx->last_stream != st && hipStreamWaitEvent(st, idx->ev1, 0) != hipSuccess) return -1.f;
+                if (pl.p.tags != nullptr) used_lists = true;
+            }
             if (hipEventRecord(e0, st) != hipSuccess) return -1.f;
             if ((e = launch_planned(idx, pl, st))) {
                 hard_error = e;
@@ -544,10 +554,23 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
                 PlanPick pk = b->pk;  // (planned once more, untimed, to learn which setting the winner ran with)
                 LaunchPlan pl;
                 const std::string keep = g_err;
-                if (plan_search(idx, S, k, L, &pl, false, &pk) == ROAR_OK) try_pick(pk.screen, pk.mode, pk.entries, idx->last_tag_protect ? 0 : 1);
-                else g_err = keep;
+                if (plan_search(idx, S, k, L, &pl, false, &pk) == ROAR_OK) {
+                    // (only where the other setting is another launch: one wave per query, pool in LDS, no hub bitmap, tags under 2^15)
+                    const int with = idx->last_tag_protect;
+                    PlanPick other = pk;
+                    other.protect = with ? 0 : 1;
+                    LaunchPlan pl2;
+                    if (pl.sel.form == ROAR_FORM_SEARCH && pl.sel.waves == 1 && !pl.sel.regpool && !pl.sel.hub &&
+                        plan_search(idx, S, k, L, &pl2, false, &other) == ROAR_OK && idx->last_tag_protect != with)
+                        try_pick(pk.screen, pk.mode, pk.entries, with ? 0 : 1);
+                } else g_err = keep;
             }
         }
+    }
+    if (used_lists && hipEventRecord(idx->ev1, st) == hipSuccess) {
+        idx->ev_valid = true;
+        idx->last_stream = st;
+        idx->last_used_tags = true;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -610,6 +633,9 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
     if (const roar_index::Calibration *c = find_calibration(idx, key)) {
         pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
         idx->last_calibrated = 1;
+    } else if (idx->max_grid > 0 && nq < (uint64_t)std::max(idx->n_cus, 1) * 12u) {
+        // a launch under a grid cap takes the calibration of the largest batches (plan_key) -- which a sample of less than one
+        // residency of the chip cannot make: defaults for this call, nothing cached
     } else if (qdev) {
         bool done = false;
         int e = calibrate_plan(idx, qdev, nq, qstride, k, L, st, &pick, &done);

@@ -360,8 +360,9 @@ __device__ __forceinline__ int quad_sum_i32(int v) {
 // qa = |q| rounded up, qb = t, qc = E.
 // CHECK (roar_screen_check_kernel, tests): row c is tested against its OWN threshold chk[c] and the verdict goes to chk[c] (1.0 = kept)
 // instead of the compaction.
+// meta: roar_screen8_split(D) -- the rows' 16 bytes of floats, a packed array behind the code rows (else they are the row's last chunk)
 template <int D, int RR, bool CHECK = false>
-__device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ scr, const uint32_t *lk, uint32_t *cid, uint32_t p0, uint32_t m,
+__device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ scr, const uint4 *__restrict__ meta, const uint32_t *lk, uint32_t *cid, uint32_t p0, uint32_t m,
                                               float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g, float *chk = nullptr) {
     constexpr int NDC = D / 16, NJ = NDC / 4, REM = D % 16;
     static_assert(NDC % 4 == 0 && (REM == 0 || REM == 8), "screening copy: row lengths of 64 k or 64 k + 8 floats");
@@ -378,7 +379,8 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
         const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
-        x[r][NJ] = row[NDC];
+        if constexpr (roar_screen8_split(D)) x[r][NJ] = meta[id[r]];
+        else x[r][NJ] = row[NDC];
     }
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
     int acc[RR];
@@ -435,7 +437,7 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
 
 // L2.  Row: D codes (D % 16 == 0), then s, lo, |x~|^2, B.  qa = |q|^2, qb = sum q_i.
 template <int D, int RR, bool CHECK = false>
-__device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
+__device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ scr, const uint4 *__restrict__ meta, const float *lq, uint32_t *cid, uint32_t p0, uint32_t m,
                                              float thr_d, float qa, float qb, uint32_t &w, int t, int g, float *chk = nullptr) {
     constexpr int NDC = D / 16, NJ = NDC / 4;
     static_assert(NDC % 4 == 0 && D % 16 == 0, "screening copy, L2: row lengths of 64 k floats");
@@ -452,7 +454,8 @@ __device__ __forceinline__ void screen8_pass(const unsigned char *__restrict__ s
         const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
-        x[r][NJ] = row[NDC];
+        if constexpr (roar_screen8_split(D)) x[r][NJ] = meta[id[r]];
+        else x[r][NJ] = row[NDC];
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
@@ -503,7 +506,7 @@ __device__ __forceinline__ float screen_threshold(float thr_d, float qd) {
 
 // lq = the f32 query in LDS, its 8-bit codes (inner product) behind it
 template <int D, bool IP, bool CHECK = false>
-__device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
+__device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const uint4 *__restrict__ meta, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
                                                  float qa, float qb, float qc, int lane, float *chk = nullptr) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
@@ -511,16 +514,16 @@ __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict
         const uint32_t *lk = reinterpret_cast<const uint32_t *>(lq + ((D + 3) & ~3));
         // rows per group and pass: four up to 256 codes (64 bytes of row per lane), two at 512 (72 bytes)
         constexpr int RB = D <= 256 ? 4 : 2;
-        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
         if constexpr (RB == 4)
-            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
-        for (; p0 < m; p0 += 16) screen8i_pass<D, 1, CHECK>(scr, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+        for (; p0 < m; p0 += 16) screen8i_pass<D, 1, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
     } else {
         if constexpr (D <= 128)
-            for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
+            for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4, CHECK>(scr, meta, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
         if constexpr (D <= 256)
-            for (; p0 + 16 < m; p0 += 32) screen8_pass<D, 2, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
-        for (; p0 < m; p0 += 16) screen8_pass<D, 1, CHECK>(scr, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
+            for (; p0 + 16 < m; p0 += 32) screen8_pass<D, 2, CHECK>(scr, meta, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
+        for (; p0 < m; p0 += 16) screen8_pass<D, 1, CHECK>(scr, meta, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
     }
     return w;
 }
@@ -1271,7 +1274,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 wave_sync();
                                 const u64 last = (RP ? lane_u64(pk, (int)L - 1) : pool[L - 1]) & ~1ull;
                                 [[maybe_unused]] const uint32_t coded = m;
-                                m = screen8_rows<SD, IP>(scr, lq, cid, m, screen_threshold(ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[11])),
+                                // (roar_screen8_split: the rows' floats sit behind the n code rows)
+                                const uint4 *meta = nullptr;
+                                if constexpr (roar_screen8_split(SD)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                    meta = reinterpret_cast<const uint4 *>(scr + (u64)(*const_cast<const uint32_t volatile *>(&ka->n)) * SD);
+#endif
+                                }
+                                m = screen8_rows<SD, IP>(scr, meta, lq, cid, m, screen_threshold(ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[11])),
                                                          __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), __uint_as_float(ctrl[10]), lane);
                                 count_traffic((u64)coded | ((u64)m << 24));
                             }
@@ -1555,7 +1565,7 @@ const void *pick_form(const RoarKernelSel &s) {
 template <bool IP, int D>
 __global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned char *__restrict__ scr, const float *__restrict__ mu,
                                                                const float *__restrict__ queries, u64 qstride, const uint32_t *__restrict__ ids, float *chk,
-                                                               uint32_t m) {
+                                                               uint32_t m, u64 n) {
     __shared__ __align__(16) float lq[D + D / 4 + 4];
     __shared__ uint32_t cid[64];
     __shared__ float th[64];
@@ -1571,7 +1581,8 @@ __global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned ch
     wave_sync();
     th[lane] = screen_threshold(th[lane], qd);
     wave_sync();
-    (void)screen8_rows<D, IP, true>(scr, lq, cid, mm, 0.f, qa, qb, qc, lane, th);
+    const uint4 *meta = roar_screen8_split(D) ? reinterpret_cast<const uint4 *>(scr + n * (u64)roar_screen8_stride(D)) : nullptr;
+    (void)screen8_rows<D, IP, true>(scr, meta, lq, cid, mm, 0.f, qa, qb, qc, lane, th);
     wave_sync();
     if ((uint32_t)lane < mm) chk[q * m + b0 + lane] = th[lane];
 }
@@ -1579,14 +1590,14 @@ __global__ void __launch_bounds__(64) roar_screen_check_kernel(const unsigned ch
 #define ROAR_CHECK_NAME2(i) roar_launch_screen_check_##i
 #define ROAR_CHECK_NAME(i) ROAR_CHECK_NAME2(i)
 extern "C" int ROAR_CHECK_NAME(ROAR_TU_IP)(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,
-                                           const uint32_t *ids, float *chk, uint32_t m, void *stream) {
+                                           const uint32_t *ids, float *chk, uint32_t m, uint64_t n_rows, void *stream) {
     constexpr bool IP = ROAR_TU_IP != 0;
     if (nq == 0 || m == 0) return 0;
     const dim3 grid((uint32_t)nq, (m + 63u) / 64u);
-    if (dim == 128) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 128>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
-    else if (dim == 512) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 512>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
+    if (dim == 128) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 128>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m, (u64)n_rows);
+    else if (dim == 512) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 512>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m, (u64)n_rows);
     else if (dim == 200 && IP) {
-        if constexpr (IP) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 200>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m);
+        if constexpr (IP) hipLaunchKernelGGL((roar_screen_check_kernel<IP, 200>), grid, dim3(64), 0, (hipStream_t)stream, scr, mu, queries, (u64)qstride, ids, chk, m, (u64)n_rows);
     } else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

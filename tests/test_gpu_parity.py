@@ -45,9 +45,18 @@ def test_search_matches_reference_golden(case, mode, golden_dir, built_lib):
             # base rows are normalised by the loader with a sequential f32 sum, the reference's
             # -Ofast build vectorises that sum: inputs differ in the last bit, so compare sets with
             # the tolerance north_star states (ids equal where distances are not within 1e-4 ties).
-            assert np.abs(r["dists"] - exp[f"dists_{L}"]).max() <= 1e-4
-            same = (r["ids"] == exp[f"ids_{L}"]).mean()
-            assert same >= 0.98, (case, L, same)
+            # north_star's criterion, position by position: distances within 1e-4, ids equal WHERE THERE IS NO DISTANCE TIE -- an id
+            # that differs must be explained by a near-tie: it stands in the reference's list within 1e-4 of the position it took, or
+            # (not in the reference's top k at all) it came in within 1e-4 of the reference's k-th distance.
+            e_ids, e_d = exp[f"ids_{L}"], exp[f"dists_{L}"]
+            assert np.abs(r["dists"] - e_d).max() <= 1e-4
+            for qi, pos in zip(*np.nonzero(r["ids"] != e_ids)):
+                where = np.nonzero(e_ids[qi] == r["ids"][qi, pos])[0]
+                if where.size:
+                    assert abs(float(e_d[qi, where[0]]) - float(e_d[qi, pos])) <= 1e-4, (case, L, qi, pos, "ids swapped without a tie")
+                else:
+                    assert abs(float(r["dists"][qi, pos]) - float(e_d[qi, -1])) <= 1e-4, (case, L, qi, pos, "a new id without a tie at the k-th")
+            assert (r["ids"] == e_ids).mean() >= 0.98, (case, L)
             assert np.array_equal(r["hops"], exp[f"hops_{L}"]) or np.abs(
                 r["hops"].astype(int) - exp[f"hops_{L}"].astype(int)).max() <= 2
             continue

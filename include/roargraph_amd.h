@@ -175,8 +175,11 @@ int roar_search_batch(roar_index *idx, const float *queries, uint64_t nq, uint32
  * (a hipStream_t, NULL = default stream); no implicit synchronisation.  Short results are reported
  * through *short_count_dev (u32, may be NULL).
  * Launches of one index on DIFFERENT streams may overlap (each takes a 16-byte launch cell from a ring of 256, zero on entry and
- * zeroed again by its last workgroup): at most 256 launches of one index may be in flight at a time, and a launch that faulted
- * leaves its cell dirty -- destroy the index after a device fault.  Launches that use per-workgroup lists in HBM (visited_mode
+ * zeroed again by its last workgroup, which also leaves the launch's stamp in it): at most 256 launches of one index may be in flight
+ * at a time.  A launch that finds its cell NOT as its predecessor should have left it -- that launch faulted, or the ring went round
+ * under it -- does not search: it stores 0xFFFFFFFF to *short_count_dev and ends (pass short_count_dev to see it); the host-buffer
+ * calls return ROAR_ERR_DEVICE for it and put the cells back themselves, a caller of this form does so with option
+ * "reset_launch_cells" once nothing of the index is in flight.  Launches that use per-workgroup lists in HBM (visited_mode
  * EXACT, or LDS with spill lists) are ordered one behind the other by an event.  "last_kernel_ns" is the duration of the most
  * recently ENQUEUED launch between its own two events on its own stream; with launches overlapping it includes what that stream
  * waited for -- use one launch at a time (or events of your own) to time a kernel.  The first search of a kind calibrates the launch
@@ -360,6 +363,9 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
+ *   "reset_launch_cells"  (any value) puts the launch cells back after a launch of the device-buffer form reported 0xFFFFFFFF in
+ *                    *short_count_dev; nothing of the index may be in flight.  ("debug_dirty_launch_cell": tests -- leaves the next
+ *                    launch's cell as a launch that died would have.)
  *   "search_kernel"  0 auto | 1 one wave per query (throughput form) | 2 four waves per query (latency form) |
  *                    3 two waves per query; auto picks four waves for batches of at most one query per CU on a dense
  *                    graph (average degree x row bytes >= 24 x 800), one wave otherwise
@@ -369,7 +375,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    longer than 170 neighbours do without); auto = for L_pq >= 100 on dense graphs (same measure);
  *                    results do not depend on it
  *   "screen"         0 auto | 1 off | 2 on: the index keeps a second copy of the base rows in 8-bit codes (made when the base rows are set:
- *                    200-d rows 256 bytes = two 128-byte lines instead of seven, 512-d rows 528 bytes = five lines instead of
+ *                    200-d rows 256 bytes = two 128-byte lines instead of seven, 512-d rows 512 + 16 bytes = four lines and a 16-byte read instead of
  *                    sixteen) and a hop scores its unvisited neighbours on it first; a neighbour whose exact key is CERTAINLY
  *                    above the pool's reject threshold (rigorous bound: this row's quantisation error norm + the rounding of
  *                    the screen's own arithmetic) is dropped there, the others are scored on the f32 rows as before -- ids,

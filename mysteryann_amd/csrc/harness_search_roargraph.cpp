@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -81,6 +82,8 @@ static void usage() {
 }
 
 int main(int argc, char **argv) {
+    // (launches that overlap on several HIP streams -- --gpus, --shards -- want a hardware queue each; read by the HIP runtime when it starts)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::string base_data_file, query_file, gt_file, projection_index_save_file, data_type = "float", dist;
     std::string evaluation_save_path, visited = "auto", bipartite_index_save_file;
     long long entry_seed = -1;

@@ -4,6 +4,16 @@
 
 using namespace roar_impl;
 
+// Launches of one index that overlap on several HIP streams need as many hardware queues as streams: a launch starts only when the
+// launch before it in the same hardware queue has finished, and the runtime maps streams onto four queues unless GPU_MAX_HW_QUEUES
+// says otherwise WHEN IT STARTS.  Set (never overwritten) when this library is loaded -- before the HIP runtime's first call in a
+// process that links it ahead of any HIP use; a process whose runtime is already up is unaffected (info key "hw_queues_env").
+namespace {
+struct HwQueuesEnv {
+    HwQueuesEnv() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queues_env;
+}  // namespace
+
 namespace roar_impl {
 
 thread_local std::string g_err;
@@ -383,8 +393,8 @@ int roar_create(roar_index **out, uint32_t dim, int metric, int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         idx->n_cus = prop.multiProcessorCount;
         HIP_TRY(roar_dev_malloc((void **)&idx->counters, 2 * sizeof(uint32_t)));
-        HIP_TRY(roar_dev_malloc((void **)&idx->ring, LAUNCH_RING * 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(idx->ring, 0, LAUNCH_RING * 4 * sizeof(uint32_t)));
+        HIP_TRY(roar_dev_malloc((void **)&idx->ring, LAUNCH_RING * 5 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(idx->ring, 0, LAUNCH_RING * 5 * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&idx->ev0));
         HIP_TRY(hipEventCreate(&idx->ev1));

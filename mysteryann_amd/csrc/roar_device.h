@@ -96,9 +96,15 @@ struct RoarSearchParams {
     uint32_t *out_scanned;
     uint32_t *short_count;
     // launch cell, u32[4] = {next query to dequeue, workgroups that have left, short queries, -}.  SearchRoarGraph
-    // kernels: zero on entry, zeroed again by the last workgroup to leave (which also stores the short count to
-    // *short_count).  Two-hop kernels: word 0 only, zeroed by the host before every launch.
+    // kernels: zero on entry, zeroed again by the last workgroup to leave, which also stores the short count to *short_count and
+    // the launch's own stamp -- its use of the cell, counted from 1 -- to *stamp (a word of its own, NOT in the cell: every workgroup
+    // loads it once, and a line that takes an atomic add per query must not be loaded, RoarStreamDev::state).  A launch that finds
+    // another stamp than its predecessor's (cell_prev) does not search: the launch that used the cell before it did not finish (a
+    // device fault, or more launches in flight than the ring has cells) -- it stores 0xFFFFFFFF to *short_count and leaves.
+    // Two-hop kernels: word 0 only, zeroed by the host before every launch.
     uint32_t *counter;
+    uint32_t *stamp;
+    uint32_t cell_prev, cell_stamp;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
     uint32_t vis_sets_log2;  // search kernel only: bit 31: the table has 3 << (value & 31) sets; bit 30: forgetful form (a
                              // full set overwrites a victim; else ids that find their set full go to the spill list below);

@@ -92,6 +92,15 @@ int fetch_results(roar_index *idx, uint64_t nq, uint32_t k, uint32_t *ids, float
     if (hops) memcpy(hops, blk + 2 * nq * k + nq, (size_t)nq * 4);
     if (scanned) memcpy(scanned, blk + 2 * nq * k + 2 * nq, (size_t)nq * 4);
     const uint32_t nshort = blk[(size_t)words - 1];
+    if (nshort == 0xFFFFFFFFu) {
+        // the launch found its cell as a launch that did not finish left it (RoarSearchParams::counter) and did not search.  This
+        // call's stream is idle now (synchronised above): every cell is put back, so the next call works -- if the device still does.
+        (void)hipMemset(idx->ring, 0, LAUNCH_RING * 5 * sizeof(uint32_t));
+        (void)hipDeviceSynchronize();
+        idx->launch_seq.store(0);
+        return fail(ROAR_ERR_DEVICE, "the search did not run: its launch cell was left dirty by an earlier launch that did not finish (a device fault, or "
+                                     "more than %u launches of this index in flight); the cells have been reset", LAUNCH_RING);
+    }
     if (nshort) {
         // message of the first short query, as the reference would have thrown it (:2408-2412)
         for (uint64_t i = 0; i < nq; ++i) {

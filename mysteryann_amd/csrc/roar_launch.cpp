@@ -67,7 +67,12 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
 
 // the launch itself: a cell of the ring, the kernel
 int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st) {
-    plan.p.counter = idx->ring + 4 * (size_t)(idx->launch_seq.fetch_add(1) % LAUNCH_RING);
+    // (the cell's stamp: which use of the cell this launch is, from 1; it expects to find its predecessor's -- RoarSearchParams::counter)
+    const uint32_t seq = idx->launch_seq.fetch_add(1);
+    plan.p.counter = idx->ring + 4 * (size_t)(seq % LAUNCH_RING);
+    plan.p.stamp = idx->ring + 4 * (size_t)LAUNCH_RING + (seq % LAUNCH_RING);  // (the stamps: an array of their own behind the cells)
+    plan.p.cell_prev = seq / LAUNCH_RING;
+    plan.p.cell_stamp = seq / LAUNCH_RING + 1u;
     int rc = roar_launch_search(&plan.p, &plan.sel, plan.grid, st);
     if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return ROAR_OK;

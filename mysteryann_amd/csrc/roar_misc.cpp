@@ -244,6 +244,26 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         idx->combine = value ? 1 : 0;
     } else if (k == "bipartite_seed") {
         idx->bp_seed = (uint64_t)value;
+    } else if (k == "reset_launch_cells") {
+        // after a launch of the device-buffer form reported 0xFFFFFFFF in *short_count_dev (its cell was left dirty by a launch that did
+        // not finish): with no launch of this index in flight, put every cell back
+        DeviceRestore keep_device_;
+        int e = use_device(idx);
+        if (e) return e;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(idx->ring, 0, LAUNCH_RING * 5 * sizeof(uint32_t)));
+        HIP_TRY(hipDeviceSynchronize());
+        idx->launch_seq.store(0);
+    } else if (k == "debug_dirty_launch_cell") {
+        // tests: leave the NEXT launch's cell as a launch that died would have (word 0 advanced, a stale stamp)
+        DeviceRestore keep_device_;
+        int e = use_device(idx);
+        if (e) return e;
+        const uint32_t seq = idx->launch_seq.load();
+        const uint32_t dirty[4] = {(uint32_t)value, 0u, 0u, 0u}, stale = seq / LAUNCH_RING + 7u;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(idx->ring + 4 * (size_t)(seq % LAUNCH_RING), dirty, sizeof dirty, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(idx->ring + 4 * (size_t)LAUNCH_RING + (seq % LAUNCH_RING), &stale, sizeof stale, hipMemcpyHostToDevice));
     } else if (k == "max_grid") {
         if (value < 0) return fail(ROAR_ERR_ARG, "max_grid must be >= 0");
         idx->max_grid = (int)value;
@@ -281,7 +301,10 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_knn_bf16") *value = idx->last_knn_bf16;
     else if (k == "last_knn_rerank_rows") *value = idx->last_knn_rerank_rows;
     else if (k == "calibrations") *value = (int64_t)idx->plan_cache.size();
-    else if (k == "screen_row_bytes") *value = roar_screen8_row_bytes(idx->dim_pad);
+    else if (k == "hw_queues_env") {  // GPU_MAX_HW_QUEUES as the environment holds it (0: unset) -- what the HIP runtime read if it started after this library was loaded
+        const char *v = getenv("GPU_MAX_HW_QUEUES");
+        *value = v ? atoll(v) : 0;
+    } else if (k == "screen_row_bytes") *value = roar_screen8_row_bytes(idx->dim_pad);
     else if (k == "launch_events_on") *value = idx->launch_events;
     else if (k == "last_combined") *value = idx->last_combined;
     else if (k == "bipartite_nodes") *value = (int64_t)idx->bp_n;

@@ -30,6 +30,24 @@
 
 namespace {
 
+// A kernel argument read WHERE IT IS USED -- once per query, or once per hop -- instead of living in scalar registers through every hop
+// (the kernels of the benchmark shapes sit at their register budget).  Rounds 2-4 did that with a `volatile` read of the argument
+// block: the compiler turns a volatile read into a system-scope VECTOR load (flat_load ... sc0 sc1: past every cache, from the memory
+// the block lives in) followed by s_waitcnt vmcnt(0) -- a whole dependent round trip in front of every hop's screening pass, which
+// also drained the speculative adjacency fetch issued just before it.  Now: a SCALAR load from the constant address space (the scalar
+// cache holds the block after the first touch), which the compiler cannot hoist because the pointer passes through an empty asm.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) RoarSearchParams *RoarKArgs;
+__device__ __forceinline__ RoarKArgs kargs() {
+    RoarKArgs ka = (RoarKArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return ka;
+}
+#define KARG(field) (kargs()->field)
+#else
+#define KARG(field) (decltype(RoarSearchParams::field){})  // (host pass of the compiler: never executed)
+#endif
+
 // LDS visited table, test-and-set of NC (1..3) ids per lane at once (one adjacency round trip; NC = the 64-word chunks
 // of the row that hold neighbours -- a row of at most 63 neighbours, the common case on a sparse graph, is one chunk).  Same table as
 // visited_filter<VIS_LDS> -- sets (2^k or 3 * 2^k) x 4 ways of u16 tags, (set, tag) <-> id a bijection, so a hit is never false -- but an
@@ -129,9 +147,9 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
 #if defined(__HIP_DEVICE_COMPILE__)
         extern __shared__ __align__(16) unsigned char smem_[];
         const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-        uint16_t *const sp = reinterpret_cast<uint16_t *>(*const_cast<uint8_t *const volatile *>(&ka->tags)) +
-                             (u64)blockIdx.x * *const_cast<const uint64_t volatile *>(&ka->tag_stride);
-        const uint32_t ep = reinterpret_cast<const volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_ctrl))[6];
+        uint16_t *const sp = reinterpret_cast<uint16_t *>(KARG(tags)) +
+                             (u64)blockIdx.x * KARG(tag_stride);
+        const uint32_t ep = reinterpret_cast<const uint32_t *>(smem_ + KARG(off_ctrl))[6];
 #else
         uint16_t *const sp = nullptr;  // (host pass of the compiler: never executed)
         const uint32_t ep = 0;
@@ -617,7 +635,7 @@ __device__ __forceinline__ uint32_t sys_load32(const uint32_t *p) { return __hip
 __device__ __forceinline__ void sys_store32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ uint32_t dev_load32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dev_store32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 lds_ptr(const volatile uint32_t *sl, int w) { return ((u64)sl[w + 1] << 32) | (u64)sl[w]; }
+__device__ __forceinline__ u64 lds_ptr(const uint32_t *sl, int w) { return ((u64)sl[w + 1] << 32) | (u64)sl[w]; }
 
 // What the stream's bookkeeping needs from the kernel arguments is read from the kernel-argument segment where it is used, once or twice
 // per QUERY, instead of living in scalar registers through every hop (the kernels of the benchmark shapes sit at their register budget).
@@ -628,20 +646,20 @@ struct StreamArgs {
     RoarStreamCell *cells;
     RoarStreamDev *dev;
     uint32_t ring_mask;
-    volatile uint32_t *sl;
+    uint32_t *sl;  // (plain LDS accesses: every hand-over is between lanes of ONE wave, behind wave_sync -- a volatile access is a flat load and a wait each)
 };
 __device__ __forceinline__ StreamArgs stream_args() {
     StreamArgs a;
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) unsigned char smem_[];
     const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    a.ctl = const_cast<RoarStreamCtl *>(*const_cast<const RoarStreamCtl *const volatile *>(&ka->s_ctl));
-    a.slots = *const_cast<const RoarStreamSlot *const volatile *>(&ka->s_slots);
-    a.done = *const_cast<RoarStreamDone *const volatile *>(&ka->s_done);
-    a.cells = *const_cast<RoarStreamCell *const volatile *>(&ka->s_cells);
-    a.dev = *const_cast<RoarStreamDev *const volatile *>(&ka->s_dev);
-    a.ring_mask = *const_cast<const uint32_t volatile *>(&ka->s_ring) - 1u;
-    a.sl = reinterpret_cast<volatile uint32_t *>(smem_ + *const_cast<const uint32_t volatile *>(&ka->off_stream));
+    a.ctl = const_cast<RoarStreamCtl *>(KARG(s_ctl));
+    a.slots = KARG(s_slots);
+    a.done = KARG(s_done);
+    a.cells = KARG(s_cells);
+    a.dev = KARG(s_dev);
+    a.ring_mask = KARG(s_ring) - 1u;
+    a.sl = reinterpret_cast<uint32_t *>(smem_ + KARG(off_stream));
 #else
     a = StreamArgs{};  // (host pass of the compiler: never executed)
 #endif
@@ -741,7 +759,7 @@ __device__ __forceinline__ uint32_t stream_fetch(const StreamArgs &a, int lane, 
 // trip per query, as the per-launch form; across a batch boundary: two.
 __device__ __forceinline__ bool stream_next(int lane, bool finish, bool was_short, uint32_t &q) {
     const StreamArgs a = stream_args();
-    volatile uint32_t *const sl = a.sl;
+    uint32_t *const sl = a.sl;
     uint32_t c = sl[16];
     uint32_t idx = 0, st = 0, f = 0, w = 0;
     bool have = false;  // a bundle for batch c has been issued (idx, st, f, w)
@@ -907,7 +925,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     uint32_t *cid = reinterpret_cast<uint32_t *>(smem + p.off_cid);
     float *lq = reinterpret_cast<float *>(smem + p.off_q);
     uint16_t *vis = reinterpret_cast<uint16_t *>(smem + p.off_vis);
-    volatile uint32_t *ctrl = reinterpret_cast<volatile uint32_t *>(smem + p.off_ctrl);
+    // (several waves per query hand words to each other through ctrl: volatile there; one wave: plain LDS accesses behind wave_sync -- a
+    // volatile access is compiled as a flat load and a wait each, four of them in front of every hop's screening pass in rounds 3-4)
+    using CtrlWord = std::conditional_t<W == 1, uint32_t, volatile uint32_t>;
+    CtrlWord *ctrl = reinterpret_cast<CtrlWord *>(smem + p.off_ctrl);
     // HUB form (long pools): rows come from the hub-annotated adjacency -- word 0 = degree | hubs << 16, the row's hub
     // neighbours first, then the others, then one u16 bitmap slot per hub neighbour -- in one round trip of 4 x 64 words
     // (such a graph has no row longer than 170); hub neighbours are tested and marked in an exact LDS bitmap (hbits,
@@ -934,7 +955,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     if (MODE == VIS_LDS && !forget) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-        if (threadIdx.x == 0) ctrl[6] = (*const_cast<uint32_t *const volatile *>(&ka->epochs))[blockIdx.x];
+        if (threadIdx.x == 0) ctrl[6] = (KARG(epochs))[blockIdx.x];
 #endif
         block_sync();
     }
@@ -949,6 +970,20 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         wave_sync();
     }
 
+    if constexpr (!STREAM) {
+        // The launch cell must be as its last user left it: that launch's stamp in the cell's stamp word (the cell is then zero).  Anything else means
+        // that launch did not finish -- a device fault, or the ring went round while it was still running -- and a search on its
+        // leftovers would skip queries silently: refuse instead (every workgroup sees the same word and leaves; the host-buffer calls
+        // turn the 0xFFFFFFFF into ROAR_ERR_DEVICE, roar_launch.cpp says how a caller of the device-buffer form recovers).
+#if defined(__HIP_DEVICE_COMPILE__)
+        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        if (dev_load32(KARG(stamp)) != KARG(cell_prev)) {
+            uint32_t *const o_short = KARG(short_count);
+            if (threadIdx.x == 0 && blockIdx.x == 0 && o_short) *o_short = 0xFFFFFFFFu;
+            return;
+        }
+#endif
+    }
     [[maybe_unused]] bool s_fin = false, s_short = false;  // (batch-stream form: a finished query waits to be counted, with the next take)
     for (;;) {
         uint32_t q = 0;
@@ -987,7 +1022,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 
         // query -> LDS (tests/test_search_roargraph.cpp:205 passes aligned_query_data + i * q_dim)
         if constexpr (STREAM) {  // (rows another launch or a copy may have rewritten since this workgroup last saw them: system-scope loads)
-            volatile uint32_t *const sl = stream_args().sl;
+            uint32_t *const sl = stream_args().sl;
             const uint32_t *qp = reinterpret_cast<const uint32_t *>(lds_ptr(sl, 0)) + (u64)q * sl[13];
             for (uint32_t i = threadIdx.x; i < p.dim; i += 64) reinterpret_cast<uint32_t *>(lq)[i] = sys_load32(qp + i);
         } else {
@@ -1006,8 +1041,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             if (e16 == 65536u) {  // (every 65 535 queries of this workgroup slot)
 #if defined(__HIP_DEVICE_COMPILE__)
                 const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-                const u64 bytes = *const_cast<const uint64_t volatile *>(&ka->tag_stride) * 2u;
-                uint8_t *sp = *const_cast<uint8_t *const volatile *>(&ka->tags) + (u64)blockIdx.x * bytes;
+                const u64 bytes = KARG(tag_stride) * 2u;
+                uint8_t *sp = KARG(tags) + (u64)blockIdx.x * bytes;
                 for (u64 i = (u64)threadIdx.x * 16; i < bytes; i += 1024 * W) *reinterpret_cast<uint4 *>(sp + i) = make_uint4(0, 0, 0, 0);
                 __threadfence();
 #endif
@@ -1031,15 +1066,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         // inner product: |q| rounded up, t, E and the codes k behind the f32 query; L2: |q|^2 and sum q_i
         if constexpr (SD > 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const bool screen_on = *const_cast<const unsigned char *const volatile *>(
-                                       &((const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr())->screen) != nullptr;
+            const bool screen_on = KARG(screen) != nullptr;
 #else
             const bool screen_on = false;
 #endif
             if (wid == 0 && screen_on) {  // (the LDS behind the query is there for the codes only when the launch has a screening copy)
                 float qa, qb, qc, qd;
 #if defined(__HIP_DEVICE_COMPILE__)
-                const float *mu = *const_cast<const float *const volatile *>(&((const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr())->screen_mu);
+                const float *mu = KARG(screen_mu);
 #else
                 const float *mu = nullptr;
 #endif
@@ -1266,7 +1300,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         if (psize == L && m > 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
                             const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-                            const unsigned char *scr = *const_cast<const unsigned char *const volatile *>(&ka->screen);
+                            const unsigned char *scr = KARG(screen);
 #else
                             const unsigned char *scr = nullptr;
 #endif
@@ -1278,7 +1312,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 const uint4 *meta = nullptr;
                                 if constexpr (roar_screen8_split(SD)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                                    meta = reinterpret_cast<const uint4 *>(scr + (u64)(*const_cast<const uint32_t volatile *>(&ka->n)) * SD);
+                                    meta = reinterpret_cast<const uint4 *>(scr + (u64)(KARG(n)) * SD);
 #endif
                                 }
                                 m = screen8_rows<SD, IP>(scr, meta, lq, cid, m, screen_threshold(ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[11])),
@@ -1360,13 +1394,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             const RoarSearchParams *ka = &p;  // (host pass of the compiler: never executed)
 #endif
             // (batch-stream form: the batch's own arrays, from the workgroup's copy of its slot; stores are write-through)
-            [[maybe_unused]] volatile uint32_t *sl = nullptr;
+            [[maybe_unused]] uint32_t *sl = nullptr;
             if constexpr (STREAM) sl = stream_args().sl;
-            uint32_t *const o_ids = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 2)) : *const_cast<uint32_t *const volatile *>(&ka->out_ids);
-            float *const o_dists = STREAM ? reinterpret_cast<float *>(lds_ptr(sl, 4)) : *const_cast<float *const volatile *>(&ka->out_dists);
-            uint32_t *const o_cmps = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 6)) : *const_cast<uint32_t *const volatile *>(&ka->out_cmps);
-            uint32_t *const o_hops = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 8)) : *const_cast<uint32_t *const volatile *>(&ka->out_hops);
-            uint32_t *const o_scanned = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 10)) : *const_cast<uint32_t *const volatile *>(&ka->out_scanned);
+            uint32_t *const o_ids = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 2)) : KARG(out_ids);
+            float *const o_dists = STREAM ? reinterpret_cast<float *>(lds_ptr(sl, 4)) : KARG(out_dists);
+            uint32_t *const o_cmps = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 6)) : KARG(out_cmps);
+            uint32_t *const o_hops = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 8)) : KARG(out_hops);
+            uint32_t *const o_scanned = STREAM ? reinterpret_cast<uint32_t *>(lds_ptr(sl, 10)) : KARG(out_scanned);
             auto put = [&](uint32_t *dst, uint32_t v) {
                 if constexpr (STREAM) sys_store32(dst, v);
                 else *dst = v;
@@ -1387,13 +1421,13 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 if (o_hops) put(o_hops + q, hops);
                 if (o_scanned) put(o_scanned + q, scanned);
                 if constexpr (STATS) {
-                    uint32_t *const o_traffic = *const_cast<uint32_t *const volatile *>(&ka->out_traffic);
+                    uint32_t *const o_traffic = KARG(out_traffic);
                     const u64 t = *traffic;
                     const uint32_t coded = (uint32_t)t & 0xFFFFFFu, passed = (uint32_t)(t >> 24) & 0xFFFFFu;
                     // every neighbour counted in cmps was scored on the f32 rows, but for those the screen dropped; + the entry point
                     *reinterpret_cast<uint4 *>(o_traffic + 4 * (u64)q) = make_uint4(coded, 1u + cmps - coded + passed, (uint32_t)(t >> 44) * 64u, 0u);
                 }
-                if (!STREAM && psize < p.k) atomicAdd(*const_cast<uint32_t *const volatile *>(&ka->counter) + 2, 1u);  // short queries of this launch
+                if (!STREAM && psize < p.k) atomicAdd(KARG(counter) + 2, 1u);  // short queries of this launch
                 if (PROF && p.prof) {
                     unsigned long long *o = p.prof + (u64)q * 16;
                     o[0] = (unsigned long long)((long long)__builtin_readcyclecounter() - tq0);
@@ -1426,7 +1460,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     if (MODE == VIS_LDS && !forget && threadIdx.x == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-        (*const_cast<uint32_t *const volatile *>(&ka->epochs))[blockIdx.x] = ctrl[6];
+        (KARG(epochs))[blockIdx.x] = ctrl[6];
 #endif
     }
     // Launch slot {next query, workgroups done, short queries, -} (one 16-byte cell of the index's ring): the last
@@ -1439,13 +1473,14 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #else
         const RoarSearchParams *ka = &p;
 #endif
-        uint32_t *const cell = *const_cast<uint32_t *const volatile *>(&ka->counter);
-        uint32_t *const o_short = *const_cast<uint32_t *const volatile *>(&ka->short_count);
+        uint32_t *const cell = KARG(counter);
+        uint32_t *const o_short = KARG(short_count);
         __threadfence();
         if (atomicAdd(cell + 1, 1u) == gridDim.x - 1u) {
             const uint32_t nshort = atomicExch(cell + 2, 0u);
             if (o_short) *o_short = nshort;
             atomicExch(cell + 1, 0u);
+            atomicExch(KARG(stamp), KARG(cell_stamp));  // (this launch has finished with the cell)
             __threadfence();
             atomicExch(cell, 0u);
         }

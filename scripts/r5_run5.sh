@@ -1,0 +1,13 @@
+timeout 1700 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r5_gpu_tests.log
+tail -5 gpurun_out/r5_gpu_tests.log
+timeout 600 python bench.py --workload webvid --steps 10 --warmup 2 --batches 2 --cpu-seconds 3 --no-host-path --no-share-probe --no-other-workloads > gpurun_out/r5_bench_webvid.json 2> gpurun_out/r5_bench_webvid.err
+timeout 600 python bench.py --workload sift --steps 10 --warmup 2 --batches 2 --cpu-seconds 3 --no-host-path --no-share-probe --no-other-workloads --force-screen > gpurun_out/r5_bench_sift_screen.json 2> gpurun_out/r5_bench_sift_screen.err
+timeout 600 python bench.py --workload sift --steps 10 --warmup 2 --batches 2 --cpu-seconds 3 --no-host-path --no-share-probe --no-other-workloads > gpurun_out/r5_bench_sift.json 2> gpurun_out/r5_bench_sift.err
+python3 - <<'PY'
+import json
+for f in ('webvid','sift_screen','sift'):
+    try:
+        r=json.load(open(f'gpurun_out/r5_bench_{f}.json')); c=r['config']; rf=r['roofline']; one=rf['one_launch_at_a_time']
+        print(f, 'value %.3fM'%(r['value']/1e6), 'serial %.3fM'%(c['value_one_launch_at_a_time']/1e6), 'L',c['L_pq'], 'screen', c['screen'][:12], 'kernel_ms one', one['kernel_ms'], 'frac one', one['frac'], 'traffic/impl', (rf['traffic'] or 0)/rf['bytes_per_launch'], 'pass', c.get('screen_pass_rate'))
+    except Exception as e: print(f, 'ERR', e)
+PY

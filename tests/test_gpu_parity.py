@@ -2339,3 +2339,41 @@ def test_builder_row_keep_cuts_long_rows_to_their_nearest_neighbours(built_lib):
         assert np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"]), L
     assert oracle.recall(r["ids"], gt, 10) > 0.9
     idx.close()
+
+
+def test_a_dirty_launch_cell_is_detected_not_searched_on(golden_dir, built_lib):
+    """A launch whose cell was left dirty by a launch that did not finish (a device fault; more than 256 launches in flight) refuses to
+    search -- 0xFFFFFFFF in *short_count_dev, ROAR_ERR_DEVICE from the host-buffer call -- instead of silently skipping the queries
+    the dead launch had taken; the host-buffer call puts the cells back, option reset_launch_cells does for the device-buffer form."""
+    import torch
+
+    from mysteryann_amd import fileio
+    from mysteryann_amd.capi import ERR_DEVICE, RoarError
+
+    exp = np.load(os.path.join(golden_dir, "ip_200.expected.npz"))
+    idx, q = _index("ip_200", golden_dir, 2)
+    r = idx.SearchRoarGraphBatch(q, K, 50)
+    assert np.array_equal(r["ids"], exp["ids_50"])
+    # host-buffer call: error, cells reset, next call fine
+    idx.set_option("debug_dirty_launch_cell", 17)
+    with pytest.raises(RoarError) as e:
+        idx.SearchRoarGraphBatch(q, K, 50)
+    assert e.value.code == ERR_DEVICE and "launch cell" in str(e.value)
+    r = idx.SearchRoarGraphBatch(q, K, 50)
+    assert np.array_equal(r["ids"], exp["ids_50"]) and np.array_equal(r["dists"], exp["dists_50"])
+    # device-buffer call: the marker, results untouched; after the reset the same buffers are filled
+    qd = torch.from_numpy(fileio.pad_rows(q)).cuda()
+    out = idx.SearchRoarGraphBatchDevice(qd, K, 50)
+    torch.cuda.synchronize()
+    out["ids"].fill_(-7)
+    idx.set_option("debug_dirty_launch_cell", 3)
+    idx.SearchRoarGraphBatchDevice(qd, K, 50, out=out)
+    torch.cuda.synchronize()
+    assert out["short"].cpu().numpy().view(np.uint32)[0] == 0xFFFFFFFF
+    assert (out["ids"].cpu().numpy() == -7).all()
+    idx.set_option("reset_launch_cells", 1)
+    idx.SearchRoarGraphBatchDevice(qd, K, 50, out=out)
+    torch.cuda.synchronize()
+    assert out["short"].cpu().numpy()[0] == 0
+    assert np.array_equal(out["ids"].cpu().numpy().view(np.uint32), exp["ids_50"])
+    idx.close()

@@ -146,7 +146,6 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
     if (__ballot(spillm != 0)) {  // (never in the forgetful form)
 #if defined(__HIP_DEVICE_COMPILE__)
         extern __shared__ __align__(16) unsigned char smem_[];
-        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
         uint16_t *const sp = reinterpret_cast<uint16_t *>(KARG(tags)) +
                              (u64)blockIdx.x * KARG(tag_stride);
         const uint32_t ep = reinterpret_cast<const uint32_t *>(smem_ + KARG(off_ctrl))[6];
@@ -652,7 +651,6 @@ __device__ __forceinline__ StreamArgs stream_args() {
     StreamArgs a;
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) unsigned char smem_[];
-    const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     a.ctl = const_cast<RoarStreamCtl *>(KARG(s_ctl));
     a.slots = KARG(s_slots);
     a.done = KARG(s_done);
@@ -954,7 +952,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     uint32_t ready_seen = 0;
     if (MODE == VIS_LDS && !forget) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
         if (threadIdx.x == 0) ctrl[6] = (KARG(epochs))[blockIdx.x];
 #endif
         block_sync();
@@ -976,7 +973,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         // leftovers would skip queries silently: refuse instead (every workgroup sees the same word and leaves; the host-buffer calls
         // turn the 0xFFFFFFFF into ROAR_ERR_DEVICE, roar_launch.cpp says how a caller of the device-buffer form recovers).
 #if defined(__HIP_DEVICE_COMPILE__)
-        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
         if (dev_load32(KARG(stamp)) != KARG(cell_prev)) {
             uint32_t *const o_short = KARG(short_count);
             if (threadIdx.x == 0 && blockIdx.x == 0 && o_short) *o_short = 0xFFFFFFFFu;
@@ -1040,7 +1036,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             uint32_t e16 = ctrl[6] + 1u;
             if (e16 == 65536u) {  // (every 65 535 queries of this workgroup slot)
 #if defined(__HIP_DEVICE_COMPILE__)
-                const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
                 const u64 bytes = KARG(tag_stride) * 2u;
                 uint8_t *sp = KARG(tags) + (u64)blockIdx.x * bytes;
                 for (u64 i = (u64)threadIdx.x * 16; i < bytes; i += 1024 * W) *reinterpret_cast<uint4 *>(sp + i) = make_uint4(0, 0, 0, 0);
@@ -1299,7 +1294,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     if constexpr (SD > 0) {  // 8-bit screen (see screen8_pass), once the pool is full
                         if (psize == L && m > 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                            const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
                             const unsigned char *scr = KARG(screen);
 #else
                             const unsigned char *scr = nullptr;
@@ -1388,11 +1382,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         if (wid == 0) {
             // The output pointers are used here only, once per query: they are read from the kernel-argument segment
             // where they are used instead of living in (spilled) scalar registers through every hop.
-#if defined(__HIP_DEVICE_COMPILE__)
-            const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-            const RoarSearchParams *ka = &p;  // (host pass of the compiler: never executed)
-#endif
             // (batch-stream form: the batch's own arrays, from the workgroup's copy of its slot; stores are write-through)
             [[maybe_unused]] uint32_t *sl = nullptr;
             if constexpr (STREAM) sl = stream_args().sl;
@@ -1459,7 +1448,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     if (MODE == VIS_EXACT && threadIdx.x == 0) p.epochs[blockIdx.x] = epoch;
     if (MODE == VIS_LDS && !forget && threadIdx.x == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
         (KARG(epochs))[blockIdx.x] = ctrl[6];
 #endif
     }
@@ -1468,11 +1456,6 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     // next, so no memset is queued in front of a launch.  (This workgroup's dequeue and short-count atomics were
     // issued before the one below, to the same L2 channel.)
     if (threadIdx.x == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const RoarSearchParams *ka = (const RoarSearchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-        const RoarSearchParams *ka = &p;
-#endif
         uint32_t *const cell = KARG(counter);
         uint32_t *const o_short = KARG(short_count);
         __threadfence();

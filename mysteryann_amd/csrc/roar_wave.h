@@ -94,29 +94,31 @@ __device__ __forceinline__ float row_distance(const float *__restrict__ rowp, co
         for (int i = 0; i < NCH; ++i) acc16<IP>(acc, x[i], q4[4 * i]);
         done = NCH;
     } else {
-        // Run-time row length: the full 16-float steps eight at a time, EVERY load of a group issued before its first FMA -- the last
-        // group too (round 4 walked its 1..7 steps one load + one FMA at a time: a 96-d row was six dependent round trips, the
-        // launch ran at 0.53 of the HBM peak).  The group's size is the same in every lane: a switch, each case straight-line loads.
+        // Run-time row length: the full 16-float steps eight at a time (every load of a group before its first FMA), then the last
+        // 1..7 steps as 4 + 2 + 1 -- each piece straight-line loads, then its FMAs in row order (round 4 walked them one load + one FMA
+        // at a time: the six steps of a 96-d row were six dependent round trips; a switch over the count with one register array was
+        // tried first and is worse than either: the array goes to scratch)
         const uint32_t nfull = dim >> 4;
         uint32_t c = 0;
-        while (c < nfull) {
-            const uint32_t nb = nfull - c < 8u ? nfull - c : 8u;
+        for (; c + 8 <= nfull; c += 8) {
             float4 x[8];
-            switch (nb) {
-                case 8: x[7] = row[4 * (c + 7)]; [[fallthrough]];
-                case 7: x[6] = row[4 * (c + 6)]; [[fallthrough]];
-                case 6: x[5] = row[4 * (c + 5)]; [[fallthrough]];
-                case 5: x[4] = row[4 * (c + 4)]; [[fallthrough]];
-                case 4: x[3] = row[4 * (c + 3)]; [[fallthrough]];
-                case 3: x[2] = row[4 * (c + 2)]; [[fallthrough]];
-                case 2: x[1] = row[4 * (c + 1)]; [[fallthrough]];
-                default: x[0] = row[4 * c];
-            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if ((uint32_t)i < nb) acc16<IP>(acc, x[i], q4[4 * (c + i)]);  // (in row order: distance.h's own accumulation order)
-            c += nb;
+            for (int i = 0; i < 8; ++i) x[i] = row[4 * (c + i)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc16<IP>(acc, x[i], q4[4 * (c + i)]);
         }
+        const uint32_t rem = nfull - c;  // (the same in every lane)
+        if (rem & 4u) {
+            const float4 x0 = row[4 * c], x1 = row[4 * (c + 1)], x2 = row[4 * (c + 2)], x3 = row[4 * (c + 3)];
+            acc16<IP>(acc, x0, q4[4 * c]), acc16<IP>(acc, x1, q4[4 * (c + 1)]), acc16<IP>(acc, x2, q4[4 * (c + 2)]), acc16<IP>(acc, x3, q4[4 * (c + 3)]);
+            c += 4;
+        }
+        if (rem & 2u) {
+            const float4 x0 = row[4 * c], x1 = row[4 * (c + 1)];
+            acc16<IP>(acc, x0, q4[4 * c]), acc16<IP>(acc, x1, q4[4 * (c + 1)]);
+            c += 2;
+        }
+        if (rem & 1u) acc16<IP>(acc, row[4 * c], q4[4 * c]);
         done = nfull;
     }
     // 16 -> 8 (distance.h:52-53 / :191-192): lanes t and t^2 now both hold s1[4*(t&1) .. +3]

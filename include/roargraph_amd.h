@@ -363,6 +363,10 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow)
  *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
+ *   "edge_floats"    0 auto | 1 off: inner product over rows whose screening codes fill whole 128-byte lines (128-d, 512-d): the scale
+ *                    and bounds of every neighbour's screening row are kept beside the adjacency (8 bytes per edge, made on first
+ *                    use) and travel with the adjacency row, so that a screened neighbour costs its code row's lines and nothing
+ *                    else; results do not depend on it (info key "last_edge_floats")
  *   "reset_launch_cells"  (any value) puts the launch cells back after a launch of the device-buffer form reported 0xFFFFFFFF in
  *                    *short_count_dev; nothing of the index may be in flight.  ("debug_dirty_launch_cell": tests -- leaves the next
  *                    launch's cell as a launch that died would have.)

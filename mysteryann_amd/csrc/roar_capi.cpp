@@ -58,8 +58,14 @@ int refuse_while_streaming(const roar_index *idx) {
     return ROAR_OK;
 }
 
+void free_edge_floats(roar_index *idx) {
+    if (idx->adj_meta) (void)hipFree(idx->adj_meta);
+    idx->adj_meta = nullptr;
+}
+
 void free_graph(roar_index *idx) {
     idx->plan_cache.clear();  // (measured on the graph that goes away)
+    free_edge_floats(idx);
     if (idx->adj) (void)hipFree(idx->adj);
     idx->adj = nullptr;
     if (idx->adj_hub) (void)hipFree(idx->adj_hub);
@@ -84,6 +90,7 @@ void free_bipartite(roar_index *idx) {
 
 void free_base(roar_index *idx) {
     idx->plan_cache.clear();
+    free_edge_floats(idx);
     if (idx->screen) (void)hipFree(idx->screen);
     if (idx->screen_mu) (void)hipFree(idx->screen_mu);
     idx->screen = nullptr;
@@ -296,8 +303,28 @@ int ensure_hub_rows(roar_index *idx) {
 // The screening copy (roar_search_v2.h, screen8_pass): + roar_screen8_bytes(dim, n) of HBM (256 per row at 200-d, 512 + 16 at 512-d), one
 // conversion pass.  Failure to make it is not an
 // error: the launch then scores every neighbour on the f32 rows, as without it.
+// RoarSearchParams::adj_meta: n x adjacency stride x 8 bytes (WebVid-2.5M shape: 2.6 GB), one pass over the adjacency.
+void ensure_edge_floats(roar_index *idx) {
+    if (idx->adj_meta || !idx->screen || !idx->adj || idx->gn != idx->n || !idx->ip || !roar_screen8_split(idx->dim_pad)) return;
+    const size_t words = (size_t)idx->gn * idx->adj_stride + ADJ_SLACK_WORDS;
+    if (roar_dev_malloc((void **)&idx->adj_meta, words * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->adj_meta = nullptr;
+        return;
+    }
+    hipError_t e = hipMemset(idx->adj_meta, 0, words * 8);
+    const void *floats = idx->screen + (size_t)idx->n * roar_screen8_stride(idx->dim_pad);
+    if (e == hipSuccess) e = (hipError_t)roar_launch_edge_floats(idx->adj, idx->adj_stride, idx->gn, floats, idx->adj_meta, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_edge_floats(idx);
+    }
+}
+
 void ensure_screen(roar_index *idx) {
     if (idx->screen && idx->screen_n == idx->n) return;
+    free_edge_floats(idx);  // (made from the copy that is being replaced)
     if (idx->screen) (void)hipFree(idx->screen);
     if (idx->screen_mu) (void)hipFree(idx->screen_mu);
     idx->screen = nullptr;

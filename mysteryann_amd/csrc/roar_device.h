@@ -80,6 +80,13 @@ struct RoarSearchParams {
     // graph, fixed-stride adjacency rows: word 0 = degree, word 1 + j = j-th out-neighbour
     const uint32_t *adj;
     uint32_t adj_stride;
+    // "edge floats" (sel.ann; inner product, rows whose screening codes fill whole lines: 128-d, 512-d): a second array parallel to the
+    // adjacency, 8 bytes per adjacency WORD -- entry w of row v = the scale and the two bf16 bounds of the screening row of v's
+    // neighbour in word w (roar_screen8i_pass) -- fetched with the adjacency row, in the same round trip, so that a screened
+    // neighbour costs its code row's whole lines and nothing else (the 16 bytes of floats were a line request of their own wherever
+    // they lived alone).  LDS: 8 bytes per candidate of a round trip at off_cmeta.
+    const unsigned long long *adj_meta;
+    uint32_t off_cmeta;
     uint32_t n;
     uint32_t ep;
     // query batch
@@ -168,6 +175,7 @@ struct RoarKernelSel {
     int gated;         // SEARCH, one wave per query, no hub / prof: queries become readable while the launch runs (RoarSearchParams::ready)
     int stats;         // SEARCH, one wave per query, no hub / prof / gate: the instantiation that fills RoarSearchParams::out_traffic
     int protect;       // SEARCH, LDS visited mode, one wave per query, pool in LDS, no hub / gate: forgetful table that keeps pool members' tags
+    int ann;           // SEARCH, LDS visited mode, one wave per query, no hub / prof / stats / gate: the neighbours' screening floats come with the adjacency row (RoarSearchParams::adj_meta)
     int stream;        // SEARCH, LDS visited mode (forgetful), one wave per query, no hub / prof / gate / stats: queries come from a ring of submitted batches
 };
 
@@ -220,6 +228,8 @@ int roar_launch_merge_topk(uint32_t nshards, uint64_t nq, uint32_t k, const uint
 // mu (inner-product form only; may be null): dim floats the codes are centred on
 int roar_launch_make_screen8(const float *base, uint64_t ld, uint32_t dim, uint64_t n, unsigned char *out, int l2, const float *mu, void *stream);  // out: roar_screen8_bytes(dim, n)
 int roar_launch_rebase_ids(uint32_t *ids, uint64_t count, uint32_t base, void *stream);
+// RoarSearchParams::adj_meta from the adjacency rows and the screening copy's packed floats (16 bytes per base row: .z scale, .w bounds)
+int roar_launch_edge_floats(const uint32_t *adj, uint32_t stride, uint64_t n, const void *row_floats, unsigned long long *out, void *stream);
 // tests: the search's own screening passes over explicit (query, row) pairs, every row against its own threshold (roar_search_v2.h,
 // roar_screen_check_kernel); _1 = inner product, _0 = L2
 int roar_launch_screen_check_1(const unsigned char *scr, const float *mu, uint32_t dim, const float *queries, uint64_t qstride, uint64_t nq,

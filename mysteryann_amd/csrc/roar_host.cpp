@@ -294,6 +294,7 @@ int roar_clone_to_device(roar_index *src, int device, roar_index **out) {
     dst->waves_per_cu = src->waves_per_cu;
     dst->vis_entries = src->vis_entries;
     dst->max_grid = src->max_grid;
+    dst->edge_floats_mode = src->edge_floats_mode;
     dst->search_kernel = src->search_kernel;
     dst->pool_form = src->pool_form;
     dst->combine = src->combine;

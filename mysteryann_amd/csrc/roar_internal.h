@@ -135,6 +135,11 @@ struct roar_index {
     unsigned char *screen = nullptr;
     float *screen_mu = nullptr;  // inner product: the mean of the base rows, which the copy's codes are centred on (dim_pad floats)
     uint64_t screen_n = 0;
+    // "edge floats": the neighbours' screening floats beside the adjacency (RoarSearchParams::adj_meta), made on first use from the graph
+    // and the screening copy, dropped when either changes
+    unsigned long long *adj_meta = nullptr;
+    int edge_floats_mode = 0;  // option "edge_floats": 0 auto (on where the kernels have the form), 1 off
+    int last_ann = 0;
     int screen_mode = 0;  // option "screen": 0 auto (on where it pays), 1 off, 2 on wherever the kernels have it
     int launch_events = 1;  // option "launch_events": 0 = no timing events around a launch ("last_kernel_ns" then keeps its last value)
     int last_screen = 0;
@@ -319,6 +324,8 @@ int ensure_tags32(roar_index *idx, uint32_t *slots_io);
 int ensure_host_csr(roar_index *idx);
 int ensure_hub_rows(roar_index *idx);
 void ensure_screen(roar_index *idx);
+void ensure_edge_floats(roar_index *idx);  // (failure to make them is not an error: adj_meta stays null and the launch reads the floats from the copy)
+void free_edge_floats(roar_index *idx);
 void make_screen_with_base(roar_index *idx);
 
 // roar_plan.cpp

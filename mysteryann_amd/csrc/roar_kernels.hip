@@ -568,6 +568,23 @@ __global__ void __launch_bounds__(256) roar_make_screen8_l2_kernel(const float *
         for (uint32_t w = meta + 4 + lane; w < stride / 4; w += 64) o32[w] = 0u;
 }
 
+// RoarSearchParams::adj_meta: entry (v, w) = {scale, bounds} of the screening row of the neighbour in word w of v's adjacency row
+// (words 1 .. degree; zeros elsewhere).  One thread per adjacency word.
+__global__ void __launch_bounds__(256) roar_edge_floats_kernel(const uint32_t *__restrict__ adj, uint32_t S, u64 n, const uint4 *__restrict__ row_floats,
+                                                               unsigned long long *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * S) return;
+    const u64 v = i / S;
+    const uint32_t w = (uint32_t)(i - v * S);
+    const uint32_t deg = adj[v * S];
+    unsigned long long e = 0ull;
+    if (w >= 1u && w <= deg) {
+        const uint4 f = row_floats[adj[i]];
+        e = (unsigned long long)f.z | ((unsigned long long)f.w << 32);
+    }
+    out[i] = e;
+}
+
 // local ids of a shard -> global ids (index-sharded configuration); "no result" stays "no result"
 __global__ void roar_rebase_ids_kernel(uint32_t *__restrict__ ids, u64 count, uint32_t base) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -754,6 +771,14 @@ extern "C" int roar_launch_distances(const RoarDistParams *p, int metric_ip, voi
         hipLaunchKernelGGL(roar_distance_kernel<true>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
     else
         hipLaunchKernelGGL(roar_distance_kernel<false>, dim3(grid), dim3(64), p->lds_bytes, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int roar_launch_edge_floats(const uint32_t *adj, uint32_t stride, uint64_t n, const void *row_floats, unsigned long long *out, void *stream) {
+    if (n == 0) return 0;
+    const u64 total = (u64)n * stride;
+    hipLaunchKernelGGL(roar_edge_floats_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj, stride, (u64)n,
+                       reinterpret_cast<const uint4 *>(row_floats), out);
     return (int)hipGetLastError();
 }
 

@@ -42,6 +42,8 @@ int search_device(roar_index *idx, const float *queries_dev, uint64_t nq, uint32
             return fail(ROAR_ERR_ARG, "internal: this kernel form cannot wait for the packing thread");
         p.ready = ready_dev;
         plan.sel.gated = 1;
+        plan.sel.ann = 0;  // (the gated form reads the screened rows' floats from the copy: no instantiation with the edge floats)
+        p.adj_meta = nullptr;
         if (plan.sel.protect) {  // (the gated form has no instantiation that keeps pool members' tags: the plain forgetful table)
             plan.sel.protect = 0;
             p.vis_sets_log2 &= ~0x20000000u;

@@ -244,6 +244,10 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
         idx->combine = value ? 1 : 0;
     } else if (k == "bipartite_seed") {
         idx->bp_seed = (uint64_t)value;
+    } else if (k == "edge_floats") {
+        if (value != 0 && value != 1) return fail(ROAR_ERR_ARG, "edge_floats must be 0 (auto) or 1 (off)");
+        if (idx->edge_floats_mode != (int)value) idx->plan_cache.clear();  // (another kernel form: measured choices no longer apply)
+        idx->edge_floats_mode = (int)value;
     } else if (k == "reset_launch_cells") {
         // after a launch of the device-buffer form reported 0xFFFFFFFF in *short_count_dev (its cell was left dirty by a launch that did
         // not finish): with no launch of this index in flight, put every cell back
@@ -301,6 +305,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
     else if (k == "last_knn_bf16") *value = idx->last_knn_bf16;
     else if (k == "last_knn_rerank_rows") *value = idx->last_knn_rerank_rows;
     else if (k == "calibrations") *value = (int64_t)idx->plan_cache.size();
+    else if (k == "last_edge_floats") *value = idx->last_ann;
     else if (k == "hw_queues_env") {  // GPU_MAX_HW_QUEUES as the environment holds it (0: unset) -- what the HIP runtime read if it started after this library was loaded
         const char *v = getenv("GPU_MAX_HW_QUEUES");
         *value = v ? atoll(v) : 0;

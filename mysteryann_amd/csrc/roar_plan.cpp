@@ -146,6 +146,19 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     if (p.screen) off += round_up(idx->dim_pad, 16);  // the query's 8-bit codes (screen8i_pass)
     p.off_vis = off;
     off += 2 * entries;
+    // "edge floats" (RoarSearchParams::adj_meta): the screened neighbours' floats travel with the adjacency row -- inner product, code rows
+    // of whole lines (128-d, 512-d), the one-wave search form without hub bitmap / phase timers / counters
+    bool ann = false;
+    if (p.screen && !bipartite && !idx->building && !use_hub && mode == ROAR_VISITED_LDS && idx->ip && roar_screen8_split(idx->dim_pad) && idx->edge_floats_mode != 1 &&
+        !idx->profile && !(idx->traffic_dev && nq <= idx->traffic_cap) && idx->search_kernel <= 1 && idx->max_deg <= 127u) {
+        ensure_edge_floats(idx);
+        ann = idx->adj_meta != nullptr;
+    }
+    if (ann) {
+        p.adj_meta = idx->adj_meta;
+        p.off_cmeta = off;
+        off += 8 * trip;
+    }
     p.off_ctrl = off;
     off += 64;  // (words 0-5 multi-wave hand-over, 6 spill epoch, 8-10 the query's side of the screen, 12-13 traffic counters)
     if (use_hub) {  // row buffer + bitmap of the hub form
@@ -180,13 +193,15 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     sel.prof = idx->profile ? 1 : 0;
     sel.hub = use_hub ? 1 : 0;
     sel.stream = stream ? 1 : 0;
+    sel.ann = ann ? 1 : 0;
+    idx->last_ann = sel.ann;
     if (stream && sel.prof) return fail(ROAR_ERR_ARG, "profile_phases: the batch-stream form has no instrumented kernel");
     if (sel.prof && !(idx->ip && idx->dim_pad == 200) && !(!idx->ip && idx->dim_pad == 128))
         return fail(ROAR_ERR_ARG, "profile_phases: the instrumented kernels exist for the 200-d inner-product and the 128-d L2 shapes only");
     int occ = 0;
     auto occupancy = [&](int *out) -> int {
         // (asked once per kernel form and LDS size: a stream of launches of one shape must not pay a runtime query each)
-        const uint64_t key = ((uint64_t)p.lds_bytes << 32) | ((uint64_t)(sel.stream & 1) << 31) | ((uint64_t)(sel.form & 7) << 28) | ((uint64_t)(sel.waves & 7) << 24) |
+        const uint64_t key = ((uint64_t)p.lds_bytes << 32) | ((uint64_t)(sel.stream & 1) << 31) | ((uint64_t)(sel.ann & 1) << 15) | ((uint64_t)(sel.form & 7) << 28) | ((uint64_t)(sel.waves & 7) << 24) |
                              ((uint64_t)(sel.visited_mode & 3) << 20) | ((uint64_t)(sel.regpool & 1) << 19) | ((uint64_t)(sel.prof & 1) << 18) |
                              ((uint64_t)(sel.hub & 1) << 17) | ((uint64_t)(sel.metric_ip & 1) << 16) | (uint64_t)(idx->dim_pad & 0xFFFF);
         for (const auto &e : idx->occ_cache)

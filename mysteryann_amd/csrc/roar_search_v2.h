@@ -379,8 +379,9 @@ __device__ __forceinline__ int quad_sum_i32(int v) {
 // instead of the compaction.
 // meta: roar_screen8_split(D) -- the rows' 16 bytes of floats, a packed array behind the code rows (else they are the row's last chunk)
 template <int D, int RR, bool CHECK = false>
+// cmeta: non-null -- the candidates' floats are in LDS, beside cid (they came with the adjacency row: RoarSearchParams::adj_meta)
 __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ scr, const uint4 *__restrict__ meta, const uint32_t *lk, uint32_t *cid, uint32_t p0, uint32_t m,
-                                              float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g, float *chk = nullptr) {
+                                              float thr_d, float qa, float qb, float qc, uint32_t &w, int t, int g, float *chk = nullptr, const uint2 *cmeta = nullptr) {
     constexpr int NDC = D / 16, NJ = NDC / 4, REM = D % 16;
     static_assert(NDC % 4 == 0 && (REM == 0 || REM == 8), "screening copy: row lengths of 64 k or 64 k + 8 floats");
     constexpr uint32_t STRIDE = roar_screen8_stride(D);
@@ -390,14 +391,23 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
     for (int r = 0; r < RR; ++r) {
         const uint32_t c = p0 + 16 * r + g;
         id[r] = cid[c < m ? c : m - 1];
+        if constexpr (roar_screen8_split(D)) {
+            if (cmeta) {
+                const uint2 f = cmeta[c < m ? c : m - 1];
+                x[r][NJ] = make_uint4(0u, 0u, f.x, f.y);
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const uint4 *row = reinterpret_cast<const uint4 *>(scr + (u64)id[r] * STRIDE);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) x[r][j] = row[t + 4 * j];
-        if constexpr (roar_screen8_split(D)) x[r][NJ] = meta[id[r]];
-        else x[r][NJ] = row[NDC];
+        if constexpr (roar_screen8_split(D)) {
+            if (!cmeta) x[r][NJ] = meta[id[r]];
+        } else {
+            x[r][NJ] = row[NDC];
+        }
     }
     wave_sync();  // (the ids of this pass are in registers: the compaction below may overwrite their slots)
     int acc[RR];
@@ -524,17 +534,17 @@ __device__ __forceinline__ float screen_threshold(float thr_d, float qd) {
 // lq = the f32 query in LDS, its 8-bit codes (inner product) behind it
 template <int D, bool IP, bool CHECK = false>
 __device__ __forceinline__ uint32_t screen8_rows(const unsigned char *__restrict__ scr, const uint4 *__restrict__ meta, const float *lq, uint32_t *cid, uint32_t m, float thr_d,
-                                                 float qa, float qb, float qc, int lane, float *chk = nullptr) {
+                                                 float qa, float qb, float qc, int lane, float *chk = nullptr, const uint2 *cmeta = nullptr) {
     const int t = lane & 3, g = lane >> 2;
     uint32_t w = 0, p0 = 0;
     if constexpr (IP) {
         const uint32_t *lk = reinterpret_cast<const uint32_t *>(lq + ((D + 3) & ~3));
         // rows per group and pass: four up to 256 codes (64 bytes of row per lane), two at 512 (72 bytes)
         constexpr int RB = D <= 256 ? 4 : 2;
-        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+        for (; p0 + 16 * (RB / 2) < m; p0 += 16 * RB) screen8i_pass<D, RB, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk, cmeta);
         if constexpr (RB == 4)
-            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
-        for (; p0 < m; p0 += 16) screen8i_pass<D, 1, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk);
+            for (; p0 + 16 < m; p0 += 32) screen8i_pass<D, 2, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk, cmeta);
+        for (; p0 < m; p0 += 16) screen8i_pass<D, 1, CHECK>(scr, meta, lk, cid, p0, m, thr_d, qa, qb, qc, w, t, g, chk, cmeta);
     } else {
         if constexpr (D <= 128)
             for (; p0 + 48 < m; p0 += 64) screen8_pass<D, 4, CHECK>(scr, meta, lq, cid, p0, m, thr_d, qa, qb, w, t, g, chk);
@@ -906,13 +916,17 @@ __device__ __forceinline__ void lds_barrier() {
 // Its own instantiation for the same reason: the policy's code costs a launch that does not use it 2 % (SIFT shape, L_pq = 170).
 // SRC: where the queries come from -- 0 the launch's own batch (p.queries, p.nq); 1 the same while a host thread is still packing the
 // rows (waits on p.ready; pageable host query blocks); 2 the batch-stream form: a ring of submitted batches (stream_next).
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, int SRC = 0, bool STATS = false, bool PROT = false>
+// ANN: the screened neighbours' floats (scale, bounds) come with the adjacency row (RoarSearchParams::adj_meta) instead of from a 16-byte
+// read per neighbour beside the code rows.
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB, int SRC = 0, bool STATS = false, bool PROT = false, bool ANN = false>
 __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     constexpr bool GATED = SRC == 1, STREAM = SRC == 2;
     static_assert(!STREAM || (W == 1 && !PROF && !HUB && !STATS && MODE == VIS_LDS), "batch-stream form: one wave per query, on-chip tag table");
     constexpr int R = 2;  // base rows per 4-lane group and scoring pass
     // padded row length with an 8-bit screening copy in front of the exact scoring (inner product, 200-d and 512-d), else 0
     constexpr int SD = (NCH == 8 && !TAIL) ? 128 : (NCH == 32 && !TAIL) ? 512 : (IP && NCH == 12 && TAIL) ? 200 : 0;
+    static_assert(!ANN || (W == 1 && !HUB && !PROF && !STATS && SRC != 1 && IP && MODE == VIS_LDS && roar_screen8_split(SD > 0 ? SD : 1)),
+                  "edge floats: inner product, code rows of whole lines, the one-wave form");
     // (a build with R = 1 and four waves per SIMD for launches with the screen on -- sixteen workgroups per CU: with the screen's f32
     // form it spilled inside the hop, 2.94 against 1.83 ms at L_pq = 50; with the integer form it fits but for 4-8 registers and buys
     // nothing: 2 048 tags, sixteen / twelve per CU, L_pq = 50 1.71 / 1.72 ms, 100 3.02 / 3.09, 500 14.0 / 14.8, 1 000 36.3 / 34.9; dropped)
@@ -1095,6 +1109,9 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 if (lane == 0) atomicAdd(traffic, v);
         };
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, pf = NONE, vcur = p.ep, deg = 0, wpos = 1;  // wpos > deg: the current row is exhausted
+        // ANN: entry w of the row's "edge floats" travels with adjacency word w, in the same lane (RoarSearchParams::adj_meta; rows of at most 127 neighbours)
+        [[maybe_unused]] u64 m0 = 0, m1 = 0;
+        [[maybe_unused]] uint2 *const cmeta = reinterpret_cast<uint2 *>(smem + (ANN ? p.off_cmeta : 0u));
         uint32_t nhub = 0;  // HUB: hub neighbours of the current row (they come first)
         const uint32_t *arow = ADJ;
         if (wid == 0) {
@@ -1103,6 +1120,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             // (plain form: the first 64 words only -- degree + up to 63 neighbours, the common case on a sparse graph; the other
             // chunks follow once the degree says they hold neighbours.  Hub form: ids and slots, the whole row.)
             a0 = arow[lane];
+            if constexpr (ANN) m0 = (KARG(adj_meta) + (u64)p.ep * AS)[lane];
             if (HUB) {
                 a1 = arow[64 + lane];
                 if (AS > 128u) a2 = arow[128 + lane];
@@ -1180,6 +1198,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         vcur = v;
                         if (v != pf) {  // the speculative fetch went to another row: pay the round trip now
                             a0 = arow[lane];
+                            if constexpr (ANN) m0 = (KARG(adj_meta) + (u64)v * AS)[lane];
                             if (HUB) {
                                 a1 = arow[64 + lane];
                                 if (AS > 128u) a2 = arow[128 + lane];
@@ -1196,6 +1215,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             deg &= 0xFFFFu;
                         } else if (deg > 63u) {  // a long row: its other chunks (a second round trip, rare on a sparse graph)
                             a1 = arow[64 + lane];
+                            if constexpr (ANN) m1 = (KARG(adj_meta) + (u64)v * AS)[64 + lane];
                             if (deg > 127u) a2 = arow[128 + lane];
                             count_traffic((u64)(deg > 127u ? 2u : 1u) << 44);
                         }
@@ -1263,6 +1283,12 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             const bool f = fresh[c] | hfresh[c];
                             const u64 fm = __ballot(f);
                             if (f) cid[m + lanes_below(fm)] = nb[c];
+                            if constexpr (ANN) {
+                                if (f) {
+                                    const u64 e = c == 0 ? m0 : m1;  // (rows of at most 127 neighbours: two chunks)
+                                    cmeta[m + lanes_below(fm)] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+                                }
+                            }
                             m += (uint32_t)__popcll(fm);
                         }
                     };
@@ -1284,8 +1310,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             whole = HUB;
                         }
                         a0 = nrow[lane];
+                        if constexpr (ANN) m0 = (KARG(adj_meta) + (u64)(nrow - ADJ))[lane];  // (the same word of the parallel array)
                         if (whole) {
                             a1 = nrow[64 + lane];
+                            if constexpr (ANN) m1 = (KARG(adj_meta) + (u64)(nrow - ADJ))[64 + lane];
                             if (AS > 128u) a2 = nrow[128 + lane];
                         }
                         if (HUB) a3 = nrow[192 + lane];
@@ -1310,7 +1338,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #endif
                                 }
                                 m = screen8_rows<SD, IP>(scr, meta, lq, cid, m, screen_threshold(ord2f((uint32_t)(last >> 32)), __uint_as_float(ctrl[11])),
-                                                         __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), __uint_as_float(ctrl[10]), lane);
+                                                         __uint_as_float(ctrl[8]), __uint_as_float(ctrl[9]), __uint_as_float(ctrl[10]), lane, nullptr,
+                                                         ANN ? cmeta : nullptr);
                                 count_traffic((u64)coded | ((u64)m << 24));
                             }
                         }
@@ -1477,10 +1506,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
 #ifndef ROAR_WPE_512
 #define ROAR_WPE_512 2
 #endif
-template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, int SRC = 0, bool STATS = false, bool PROT = false>
+template <int MODE, bool IP, int NCH, bool TAIL, int W, bool RP, bool PROF, bool HUB = false, int SRC = 0, bool STATS = false, bool PROT = false, bool ANN = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(NCH > 16 ? ROAR_WPE_512 : 3, NCH > 16 ? ROAR_WPE_512 : 3)))
 roar_search_v2_kernel(const RoarSearchParams p) {
-    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, SRC, STATS, PROT>(p);
+    search_v2<MODE, IP, NCH, TAIL, W, RP, PROF, HUB, SRC, STATS, PROT, ANN>(p);
 }
 
 // The same kernel under its own symbol for the searches the graph builder issues (LDS visited mode, one wave per
@@ -1500,6 +1529,21 @@ const void *pick_form(const RoarKernelSel &s) {
                       : (const void *)roar_build_search_v2_kernel<IP, NCH, TAIL, false>;
         else
             return nullptr;
+    }
+    if (s.ann) {  // the neighbours' screening floats come with the adjacency row: inner product, 128-d / 512-d, one wave per query, on-chip tag table
+        if constexpr (MODE == VIS_LDS && IP && !TAIL && (NCH == 8 || NCH == 32)) {
+            if (s.waves != 1 || s.hub || s.gated || s.prof || s.stats || (s.protect && rp)) return nullptr;
+            if (s.stream) {
+                if (s.protect) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 2, false, true, true>;
+                return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, 2, false, false, true>
+                          : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 2, false, false, true>;
+            }
+            if (s.protect) return (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 0, false, true, true>;
+            return rp ? (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, true, false, false, 0, false, false, true>
+                      : (const void *)roar_search_v2_kernel<MODE, IP, NCH, TAIL, 1, false, false, false, 0, false, false, true>;
+        } else {
+            return nullptr;
+        }
     }
     if (s.stream) {  // batch-stream form: one wave per query, forgetful on-chip tag table, queries from a ring of submitted batches
         if constexpr (MODE == VIS_LDS) {

@@ -2377,3 +2377,57 @@ def test_a_dirty_launch_cell_is_detected_not_searched_on(golden_dir, built_lib):
     assert out["short"].cpu().numpy()[0] == 0
     assert np.array_equal(out["ids"].cpu().numpy().view(np.uint32), exp["ids_50"])
     idx.close()
+
+
+@pytest.mark.parametrize("d", [512, 128])
+def test_edge_floats_form_changes_no_result(d, built_lib):
+    """Option edge_floats (round 5): inner product over rows whose screening codes fill whole lines -- the scale and bounds of every
+    neighbour's screening row travel with the adjacency row (RoarSearchParams::adj_meta) instead of being read beside the code rows.
+    With it and without it: ids, distances, hops, cmps equal, and equal to the oracle's; per-launch call and batch stream; a graph
+    with rows of up to 120 neighbours (second chunk) and zero-degree nodes; pools in registers and in LDS."""
+    import oracle
+    import torch
+
+    from mysteryann_amd import index as mi
+
+    n, nq = 6000, 200
+    rng = np.random.default_rng(d)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    deg = rng.integers(0, 121, n)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(deg)
+    nbrs = rng.integers(0, n, int(off[-1])).astype(np.uint32)
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(9, off, nbrs)
+    idx.set_option("calibrate", 0), idx.set_option("screen", 2), idx.set_option("visited_mode", 3)
+    qd = torch.from_numpy(q).cuda()
+    for L in (20, 64, 65, 300):
+        o = oracle.search_batch(base, off, nbrs, 9, q, K, L, 1, threads=8)
+        res = {}
+        for ef in (1, 0):
+            idx.set_option("edge_floats", ef)
+            r = idx.SearchRoarGraphBatch(q, K, L)
+            assert idx.info("last_edge_floats") == (0 if ef else 1), (d, L, ef)
+            assert idx.info("last_screen") == 1
+            for key in ("ids", "dists", "hops"):
+                assert np.array_equal(r[key], o[key]), (d, L, ef, key)
+            res[ef] = r
+        assert np.array_equal(res[0]["cmps"], res[1]["cmps"]), (d, L)
+        with idx.OpenSearchStream(K, L) as st:  # (edge floats on)
+            t, out = st.submit(qd)
+            assert st.wait(t) == 0
+            assert np.array_equal(out["ids"].cpu().numpy().view(np.uint32), o["ids"]), (d, L, "stream")
+            assert np.array_equal(out["dists"].cpu().numpy(), o["dists"]), (d, L, "stream")
+    # a new graph and new base rows forget the floats of the old ones
+    idx.SetProjectionGraph(3, off, nbrs[::-1].copy())
+    o = oracle.search_batch(base, off, nbrs[::-1].copy(), 3, q, K, 50, 1, threads=8)
+    r = idx.SearchRoarGraphBatch(q, K, 50)
+    assert idx.info("last_edge_floats") == 1 and np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
+    idx.SetBaseData(base[::-1].copy())
+    o = oracle.search_batch(base[::-1].copy(), off, nbrs[::-1].copy(), 3, q, K, 50, 1, threads=8)
+    r = idx.SearchRoarGraphBatch(q, K, 50)
+    assert idx.info("last_edge_floats") == 1 and np.array_equal(r["ids"], o["ids"]) and np.array_equal(r["dists"], o["dists"])
+    idx.close()

@@ -451,7 +451,8 @@ int roar_search_stream_close(roar_stream *s) {
     {
         std::unique_lock<std::mutex> lk(s->mu);
         (void)use_device(s->idx);
-        if (!s->broken && s->planned) rc = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream");
+        if (s->broken) rc = fail(ROAR_ERR_DEVICE, "search stream: an earlier call failed; the stream's buffers are not freed (workgroups may still be reading them)");
+        else if (s->planned) rc = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream");
         if (rc == ROAR_OK) {
             // every batch is complete: the workgroups find nothing published and leave; their launches end
             for (auto &c : s->lanes)

@@ -10,7 +10,7 @@ from mysteryann_amd import index as mi, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--builder", default="reference")
-ap.add_argument("--graph-cache", default="/tmp/r2_graph.index")
+ap.add_argument("--graph-cache", default="/tmp/roar_graph.index")
 ap.add_argument("--L", type=int, nargs="+", default=[55])
 ap.add_argument("--nqs", type=int, nargs="+", default=[1, 256, 1250, 2500, 10000])
 ap.add_argument("--vis", type=int, default=1)

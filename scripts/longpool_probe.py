@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from _graph import t2i_index
 ap = argparse.ArgumentParser()
-ap.add_argument("--graph-cache", default="/tmp/r4_graph.index")
+ap.add_argument("--graph-cache", default="/tmp/roar_graph.index")
 ap.add_argument("--L", type=int, nargs="+", default=[200, 500, 1000, 2000])
 ap.add_argument("--nq", type=int, default=10000)
 ap.add_argument("--tables", type=int, nargs="+", default=[2048, 4096, 8192], help="forgetful on-chip table sizes (tags; 3 * 2^k allowed)")

@@ -9,7 +9,7 @@ from _graph import t2i_index
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
-ap.add_argument("--graph-cache", default="/tmp/r4_graph.index")
+ap.add_argument("--graph-cache", default="/tmp/roar_graph.index")
 ap.add_argument("--L", type=int, nargs="+", default=[50, 100, 500, 1000, 2000])
 ap.add_argument("--nqs", type=int, nargs="+", default=[1250, 2500, 10000])
 args = ap.parse_args()

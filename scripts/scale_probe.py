@@ -9,7 +9,7 @@ import torch
 from _graph import t2i_index
 
 L, K, B, STEPS = int(os.environ.get("L_PQ", "55")), 10, 8, 64
-idx, base, queries = t2i_index(10_000_000, 10_000 * B, "reference", 0, "/tmp/r3_graph2.index")
+idx, base, queries = t2i_index(10_000_000, 10_000 * B, "reference", 0, "/tmp/roar_graph.index")
 dev = queries.device
 main = torch.cuda.current_stream(dev)
 side = [torch.cuda.Stream(dev) for _ in range(16)]

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 from _graph import t2i_index
 
-idx, base_t, queries = t2i_index(10_000_000, 10_000, "reference", 0, "/tmp/r3_graph2.index")
+idx, base_t, queries = t2i_index(10_000_000, 10_000, "reference", 0, "/tmp/roar_graph.index")
 ep, off, nbrs = idx.GetProjectionGraph()
 off = off.astype(np.int64)
 base = base_t.cpu().numpy()

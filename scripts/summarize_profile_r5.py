@@ -45,7 +45,10 @@ summary = {
         "last_dispatches_ms_rocprof": [(e - s) / 1e6 for s, e, _ in last],
         "note": "a dispatch of the batch-stream form lives from the first submit that finds fewer workgroups alive than the chip holds to the "
                 "moment its last workgroup finds nothing published left: the timed loop's K steps are served by the last one or two of them",
-        "ms_per_step_rocprof": (max(e for _, e, _ in last) - min(s for s, _, _ in last)) / 1e6 / steps if last else None,
+        # the warm-up steps and the timed steps are separated by a wait that lets every workgroup exit, so the LAST dispatch is the timed
+        # loop's alone (the one before it served the warm-up)
+        "ms_per_step_rocprof": (last[-1][1] - last[-1][0]) / 1e6 / steps if last else None,
+        "ms_per_step_rocprof_is": "duration of the LAST dispatch of the stream kernel (the timed loop's steps; the one before it served the warm-up) / steps",
         "kernel_ms_device_clock_same_process": tf["roofline"]["kernel_ms"], "regime_same_process": tf["config"]["value_regime"],
         "kernel_ms_device_clock_bench_run": bench["roofline"]["kernel_ms"], "regime_bench_run": bench["config"]["value_regime"],
         "traffic_bytes_per_launch_pmc_bench_run": bench["roofline"].get("traffic"), "frac_bench_run": bench["roofline"].get("frac")},

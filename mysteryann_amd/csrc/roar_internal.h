@@ -91,7 +91,7 @@ extern "C" int roar_knn_run(const float *q, uint64_t ldq, uint32_t nq, const flo
 extern "C" {  // roar_knn_bf16.hip
 uint32_t roar_knn_bf16_row_quads(uint32_t dim);
 int roar_knn_bf16_convert(const float *src, uint64_t ld, uint32_t dim, uint64_t n, uint64_t n_pad, void *dst, float *sqnorm, uint32_t *max_sq_bits,
-                          void *stream);
+                          int aug, void *stream);
 int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b, uint64_t ldb, uint64_t n, uint32_t dim, int ip, uint32_t k,
                       uint32_t cap, const void *bb, const float *bnorm, void *qb, void *cand, void *cursor, void *tau, void *ea, void *kq,
                       void *overflow_dev, uint32_t *rerank_rows_dev, uint32_t *ids, float *dists, uint32_t *overflowed, void *stream);

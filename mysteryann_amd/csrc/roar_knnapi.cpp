@@ -66,7 +66,7 @@ int exact_knn_bf16(roar_index *idx, const float *queries_dev, uint64_t nq, uint3
     if (idx->dim_pad > 512) return ROAR_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     const uint32_t KQ = roar_knn_bf16_row_quads(idx->dim_pad);
-    const uint64_t chunk = std::min<uint64_t>(nq, 65536), chunk_pad = (chunk + 255) / 256 * 256;
+    const uint64_t chunk = std::min<uint64_t>(nq, 65536), chunk_pad = (chunk + 511) / 512 * 512;
     void *bb = nullptr, *bnorm = nullptr, *xmax = nullptr, *qb = nullptr, *cand = nullptr, *cursor = nullptr, *tau = nullptr, *slack = nullptr,
          *thr = nullptr, *ovf = nullptr, *rr = nullptr;
     auto cleanup = [&]() {
@@ -89,7 +89,7 @@ int exact_knn_bf16(roar_index *idx, const float *queries_dev, uint64_t nq, uint3
     he = hipMemsetAsync(xmax, 0, 4, st);
     if (he == hipSuccess) he = hipMemsetAsync(rr, 0, 4, st);
     if (he == hipSuccess)
-        he = (hipError_t)roar_knn_bf16_convert(idx->base, idx->ld, idx->dim_pad, idx->n, idx->n, bb, (float *)bnorm, (uint32_t *)xmax, st);
+        he = (hipError_t)roar_knn_bf16_convert(idx->base, idx->ld, idx->dim_pad, idx->n, idx->n, bb, (float *)bnorm, (uint32_t *)xmax, idx->ip ? 1 : 2, st);
     if (he == hipSuccess) he = hipMemcpyAsync(&xbits, xmax, 4, hipMemcpyDeviceToHost, st);
     if (he == hipSuccess) he = hipStreamSynchronize(st);
     if (he != hipSuccess) {

@@ -17,19 +17,26 @@
 //   3. every row gets an interval [lo, hi] = d^ -+ eps around its exact distance.  If U is the k-th smallest hi over any set of rows, k
 //      rows have exact distances <= U, so the exact k-th distance t <= U, and every row of the exact top k has lo <= t <= U: a pass
 //      admits the rows with lo <= U_prev (U of the previous, sparser sample: its k rows are in this one too, so U <= U_prev and nothing
-//      with hi <= U is missed), keyed by hi; the selection finds U among them; after the last pass the rows with lo <= U go on;
+//      with hi <= U is missed), keyed by hi; the selection finds U among them -- also BETWEEN the launches of one pass (round 5: the
+//      k-th smallest hi of what the pass has admitted so far is such a bound too; the smaller of the two is kept) --; after the last
+//      pass the rows with lo <= U go on;
 //   4. those (~1.3-2 k rows per query) are scored on the f32 rows by the search kernels' own distance routine -- the reference's
 //      summation order (roar_wave.h row_distance = distance.h:39-89,179-223), bit-identical to DistanceInnerProduct / DistanceL2 -- and
 //      sorted by (distance, id).  The result is the exact top k under the reference's own arithmetic, whatever the bf16 pass did.
 //
 // GEMM tile: a workgroup of 8 waves owns 256 queries (wave w: 32 of them, its A fragments -- 13 x 4 VGPRs at D = 200 -- stay in
 // REGISTERS for the whole slice) and walks a slice of the sample in tiles of 64 base rows, NBUF tiles deep in LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, uniform tile base + 32-bit lane offset).  Per tile and wave two blocks of 32 rows:
-// K/16 MFMAs of 32x32x16 each, and between a block's MFMAs the 16 verdicts (one fma, one compare: a lane mask in scalar registers)
-// of the block finished before; admitted elements (rare) are staged in LDS.  1-D grid, query tile fastest: the workgroups that run
-// together stream the same slice (L2 / Infinity Cache), every base row leaves HBM about once per pass.
-// Measured (profiles/r04_knn_kernel_stats.txt, r04_knn_counters.txt, r04_mfma_probe.txt): last pass 0.39 of the bf16 peak, MFMA
-// busy 0.42; a loop of this shape with nothing but the MFMAs, the LDS reads and the verdicts reaches 0.72.
+// (global_load_lds_dwordx4: no staging registers, uniform tile base + 32-bit lane offset; issued one at a time between the MFMAs).  Per
+// tile and wave two blocks of 32 rows: K/16 MFMAs of 32x32x16 each, then ONE more MFMA that forms the admission test itself (the
+// verdict columns: knn_pass_bf16_kernel, "The verdict as one more MFMA"), and between the next block's MFMAs the maximum of the sixteen
+// verdict registers and one compare; admitted elements are staged in LDS.  Two tiles between two barriers.  1-D grid, query tile
+// fastest: the workgroups that run together stream the same slice (L2 / Infinity Cache), every base row leaves HBM about once per
+// pass.  A pass over many slices is up to eight launches with a selection after each: the bound tightens while the pass runs.
+// Measured: round 4 (profiles/r04_knn_kernel_stats.txt, r04_knn_counters.txt, r04_mfma_probe.txt) last pass 281 ms = 0.39 of the bf16
+// peak, one 65 536-query block of the builder's lists 0.340 s; round 5 (profiles/r05_knn_forms.txt, r05_knn_kernel_stats.csv):
+// 0.281 s per block (512-d, 2.5 M rows: 0.241 -> 0.186 s; 128-d, 1 M rows: 0.071 -> 0.058 s).  What the round learned about the rest:
+// with nothing admitted, no loads and no barrier the loop still takes 0.6 of its time at the nominal peak -- the shader clock, by the
+// instrumented kernel's cycle counts against wall time, falls from ~2.45 GHz to ~2.1 GHz as the matrix cores fill.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WP
 
     const uint32_t ntiles = (uint32_t)((s1 - s0 + BT - 1) / BT);
 #pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i) dma((uint32_t)i, s0 + (u64)i * BT);
+    for (int i = 0; i < ((NBUF == 4 && KS <= 16) ? 2 : NBUF - 1); ++i) dma((uint32_t)i, s0 + (u64)i * BT);  // (see TPB at the main loop)
 
     // (a quarter of the blocks: ~k x ratio admissions per query and pass): the admitted elements of one block -> the staging list.
     // S = the block's verdict sums (above), acc its clean scores.
@@ -538,56 +545,79 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WP
         }
     };
     if constexpr (PROF) c0 = (long long)__builtin_readcyclecounter();
-    for (uint32_t ti = 0; ti < ntiles; ++ti) {
-        const u64 t0 = s0 + (u64)ti * BT;
-        const uint32_t b = ti % NBUF;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
+    // TPB tiles between two barriers.  TPB = 1: NBUF - 1 tiles in flight, a counted wait per tile (round 4).  TPB = 2 (NBUF = 4): the loop
+    // body is a PAIR of tiles -- one wait (everything this thread loaded: the pair), one barrier, then the pair's four blocks with the next
+    // pair's loads between the MFMAs of its two first blocks.  From a barrier to the first MFMA behind it the matrix cores of the CU idle
+    // (both waves of every SIMD stand there: ~1 000 of an iteration's ~3 000 cycles, phase counters of the instrumented form), and this
+    // halves how often that happens.
+    constexpr int TPB = (NBUF == 4 && KS <= 16) ? 2 : 1;
+    const uint32_t ngroups = (ntiles + TPB - 1) / TPB;
+    for (uint32_t tg = 0; tg < ngroups; ++tg) {
+        // Everything the tiles need that does not wait for them -- where their fragments are, where the next loads go -- is worked out
+        // BEFORE the barrier, under the last MFMAs of the tile before.
+        DmaTile dt[TPB];
+        uint32_t a0[TPB], a1[TPB], an[TPB];
+#pragma unroll
+        for (int u = 0; u < TPB; ++u) {
+            const uint32_t ti = tg * TPB + u, b = ti % NBUF;
+            const uint32_t tn = TPB == 1 ? ti + NBUF - 1 : ti + TPB;  // the tile whose loads go out under tile ti's first block
+            dt[u] = dma_prepare(tn % NBUF, s0 + (u64)tn * BT);
+            const uint4 *bufc = bufs + (size_t)b * JT * NT;
+            a0[u] = lds_addr(bufc + (size_t)r * KQ + h), a1[u] = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
+            an[u] = lds_addr(nrm + b * 64 + r);
+            asm volatile("" ::"s"(dt[u].tb), "s"(dt[u].nb), "s"(dt[u].lb), "v"(a0[u]), "v"(a1[u]), "v"(an[u]));  // (in their registers here)
+        }
+        if constexpr (TPB == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (JT + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tick(0);
         if (!(p.debug & 8)) __builtin_amdgcn_s_barrier();
         tick(1);
-        const DmaTile dt = dma_prepare((ti + NBUF - 1) % NBUF, t0 + (u64)(NBUF - 1) * BT);
-        if (!dt.fast && !(p.debug & 4)) dma_slow(dt, t0 + (u64)(NBUF - 1) * BT);
-        const uint4 *bufc = bufs + (size_t)b * JT * NT;
-        const uint32_t a0 = lds_addr(bufc + (size_t)r * KQ + h), a1 = lds_addr(bufc + (size_t)(32 + r) * KQ + h);
-        float bn0, bn1;  // issued here, first used a block later: LDS operations complete in order, the block's counted waits cover them
-        lds_read2_f32_nowait(lds_addr(nrm + b * 64 + r), bn0, bn1);
-        u64 any[QH];
-        float gm[QH][5];
-        tick(2);
-        // rows 0..31 of this tile, under them the verdict of rows 32..63 of the tile before (a whole tile: no column mask)
-        // (the tile's loads: load j behind step j * KS / (JT + 1) + 1 of the first block)
-        block(acc0, S0, a0, S1, any, gm, [&](auto c) {
-            constexpr int ks = decltype(c)::value;
-            static_for<0, JT + 1>([&](auto cj) {
-                constexpr int j = decltype(cj)::value;
-                if constexpr ((j * KS) / (JT + 1) + 1 == ks || (ks == KS - 1 && (j * KS) / (JT + 1) + 1 > ks)) {
-                    if (dt.fast && !(p.debug & 4)) dma_one(dt, j);
-                }
-            });
-        });
-        tick(3);
 #pragma unroll
-        for (int qh = 0; qh < QH; ++qh)
-            if (nonzero(any[qh])) admit(acc1[qh], S1[qh], gm[qh], qh, ~0ull, t0 - BT, 1, bn1p);  // (the first tile: S1 is -1 everywhere)
-        tick(4);
-        // rows 32..63, under them the verdict of rows 0..31
-        asm volatile("" : "+v"(bn0), "+v"(bn1));  // (usable from here: behind the first block's waits)
-        block(acc1, S1, a1, S0, any, gm, [](auto) {});
-        tick(3);
-        {
-            u64 cm = ~0ull;
-            if (t0 + 32 > s1) cm = __ballot(t0 + r < s1);
+        for (int u = 0; u < TPB; ++u) {
+            const uint32_t ti = tg * TPB + u;
+            const u64 t0 = s0 + (u64)ti * BT;
+            const u64 tnext = s0 + (u64)(TPB == 1 ? ti + NBUF - 1 : ti + TPB) * BT;
+            if (!dt[u].fast && !(p.debug & 4)) dma_slow(dt[u], tnext);
+            u64 any[QH];
+            float gm[QH][5];
+            tick(2);
+            // rows 0..31 of this tile, under them the verdict of rows 32..63 of the tile before (a whole tile: no column mask)
+            // (the next loads: load j behind step j * KS / (JT + 1) + 1 of the first block)
+            float bn0, bn1;  // issued behind the block's first fragment reads, first used a block later: LDS operations complete in order, the block's counted waits cover them
+            block(acc0, S0, a0[u], S1, any, gm, [&](auto c) {
+                constexpr int ks = decltype(c)::value;
+                if constexpr (ks == 0) lds_read2_f32_nowait(an[u], bn0, bn1);
+                static_for<0, JT + 1>([&](auto cj) {
+                    constexpr int j = decltype(cj)::value;
+                    if constexpr ((j * KS) / (JT + 1) + 1 == ks || (ks == KS - 1 && (j * KS) / (JT + 1) + 1 > ks)) {
+                        if (dt[u].fast && !(p.debug & 4)) dma_one(dt[u], j);
+                    }
+                });
+            });
+            tick(3);
 #pragma unroll
             for (int qh = 0; qh < QH; ++qh)
-                if (nonzero(any[qh] & cm)) admit(acc0[qh], S0[qh], gm[qh], qh, cm, t0, 0, bn0);
+                if (nonzero(any[qh])) admit(acc1[qh], S1[qh], gm[qh], qh, ~0ull, t0 - BT, 1, bn1p);  // (the first tile: S1 is -1 everywhere)
+            tick(4);
+            // rows 32..63, under them the verdict of rows 0..31
+            asm volatile("" : "+v"(bn0), "+v"(bn1));  // (usable from here: behind the first block's waits)
+            block(acc1, S1, a1[u], S0, any, gm, [](auto) {});
+            tick(3);
+            {
+                u64 cm = ~0ull;
+                if (t0 + 32 > s1) cm = __ballot(t0 + r < s1);
+#pragma unroll
+                for (int qh = 0; qh < QH; ++qh)
+                    if (nonzero(any[qh] & cm)) admit(acc0[qh], S0[qh], gm[qh], qh, cm, t0, 0, bn0);
+            }
+            tick(4);
+            bn1p = bn1;
         }
-        tick(4);
-        bn1p = bn1;
-        // The staged admissions leave when the list is half full -- decided for everybody by one thread, a tile ahead, through LDS: a flush
-        // waits for every load in flight (stores and loads leave the counter out of order), i.e. it drains the LDS-DMA pipeline; every 32
-        // tiles, as it was, that cost 170 cycles per tile (phase counters of the instrumented form).
-        if ((ti & 31u) == 30u && tid == 0) lds_write_b32(lds_addr(sflag), lds_read_b32(lds_addr(scnt)) > (uint32_t)(HCAP / 2) ? 1u : 0u);
-        if ((ti & 31u) == 31u && !(p.debug & 2)) {
+        // The staged admissions leave when the list is half full -- decided for everybody by one thread, an iteration ahead, through LDS: a
+        // flush waits for every load in flight (stores and loads leave the counter out of order), i.e. it drains the LDS-DMA pipeline;
+        // every 32 tiles, as it was, that cost 170 cycles per tile (phase counters of the instrumented form).
+        if ((tg & 15u) == 14u && tid == 0) lds_write_b32(lds_addr(sflag), lds_read_b32(lds_addr(scnt)) > (uint32_t)(HCAP / 2) ? 1u : 0u);
+        if ((tg & 15u) == 15u && !(p.debug & 2)) {
             if (__builtin_amdgcn_readfirstlane(lds_read_b32(lds_addr(sflag)))) flush();
         }
         tick(5);
@@ -599,8 +629,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WP
             atomicAdd(p.prof + 6, (unsigned long long)ntiles);
         }
     }
-    {  // the last tile's second block
-        const u64 t0 = s0 + (u64)(ntiles - 1) * BT;
+    {  // the last tile's second block (TPB = 2, an odd number of tiles: the loop went one tile past the slice -- nothing of it is anybody's)
+        const u64 t0 = s0 + (u64)(ngroups * TPB - 1) * BT;
         const u64 cm = __ballot(t0 + 32 + r < s1);
 #pragma unroll
         for (int qh = 0; qh < QH; ++qh) {
@@ -850,13 +880,14 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         // A pass over many slices goes in G launches with a selection after each: U, read by a workgroup when it starts, is then the k-th
         // smallest hi of everything admitted SO FAR in this pass as well (any k rows bound the k-th distance; the selection keeps the
         // smaller of the old and the new bound) -- after the first quarter of the rows it is the bound of a sample five times denser than
-        // the previous pass's, and the rest of the pass admits accordingly fewer rows: T2I-10M, k = 100, last pass: 3 060 -> ~1 100 rows
-        // per query, and an admitting block is the expensive thing in the pass kernel (round 5, profiles/r05_knn_forms.txt).
+        // the previous pass's, and the rest of the pass admits accordingly fewer rows: T2I-10M, k = 100, last pass: 3 060 rows per query in one
+        // launch, 1 061 in four, 799 in eight -- and an admitting block is the expensive thing in the pass kernel (round 5,
+        // profiles/r05_knn_forms.txt: 0.340 -> 0.281 s per 65 536-query block with everything of the round; 512-d 0.241 -> 0.186).
         static const int split_env = [] {
             const char *e = getenv("ROAR_KNN_SPLIT");
             return e ? atoi(e) : 0;
         }();
-        const uint64_t G = split_env > 0 ? std::min<uint64_t>((uint64_t)split_env, nslices) : nslices >= 16 ? 4 : nslices >= 8 ? 2 : 1;
+        const uint64_t G = std::min<uint64_t>(split_env > 0 ? (uint64_t)split_env : 8, nslices);
         const bool timed = pass == P - 1 && getenv("ROAR_KNN_TIME");  // debug: the last pass alone, by the device's clock
         static hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (timed) {

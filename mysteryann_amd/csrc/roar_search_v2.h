@@ -1100,6 +1100,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
         // cursor `cur` = index of the closest unexpanded entry.
         u64 pk = ~0ull;
         uint32_t psize = 1, cur = 0, cmps = 0, hops = 0, scanned = 0;
+        // LDS pool: every entry below `front` is expanded except at most `ub` of them (the merge counts what it puts there): once those are
+        // taken, the search for the next unexpanded entry starts AT the front instead of walking the expanded entries between a survivor
+        // that landed low and the front, 64 per LDS round trip (L_pq = 1 000: four of them per hop, round 5)
+        [[maybe_unused]] uint32_t front = 0, ub = 0;
         // what the query asks the memory side for, beside cmps (RoarSearchParams::out_traffic): one packed LDS word, ctrl[12..13] =
         // rows scored on the 8-bit copy | rows that passed it << 24 | 64-word adjacency chunks fetched << 44 -- one LDS add of
         // lane 0 where something is fetched, no register lives through the hop for it
@@ -1173,8 +1177,10 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                             v = (uint32_t)e >> 1;
                             if (lane == 0) pool[cur] = e | 1ull;
                             wave_sync();
+                            if (cur < front) ub = ub ? ub - 1u : 0u;
+                            else front = cur + 1u, ub = 0;
                             uint32_t found = psize;
-                            for (uint32_t c = cur + 1; c < psize; c += 64) {
+                            for (uint32_t c = (ub == 0 && front > cur + 1u) ? front : cur + 1u; c < psize; c += 64) {
                                 const uint32_t kidx = c + (uint32_t)lane;
                                 const bool unf = kidx < psize && !(pool[kidx] & 1ull);
                                 const u64 b = __ballot(unf);
@@ -1184,6 +1190,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 }
                             }
                             cur = found;
+                            if (found >= front) front = found, ub = 0;  // (nothing unexpanded below it)
                         }
                     }
                     if (!done) {
@@ -1400,7 +1407,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     else {
                         TagProtect tp;
                         if (MODE == VIS_LDS && protect) tp.vis = vis, tp.sets_mask = sets_mask, tp.sets_log2 = sets_log2, tp.three = sets3;
-                        merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp);
+                        merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp, &front, &ub);
                     }
                 }
                 if (PROF) t_merge += (long long)__builtin_readcyclecounter() - s0;

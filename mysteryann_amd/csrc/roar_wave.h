@@ -253,8 +253,11 @@ __device__ __forceinline__ void tag_protect(const TagProtect &tp, uint32_t id, b
 // segment) and finish with log2(psize / 64) per-lane probes instead of log2(psize); (2) the pool is shifted SEGMENT by segment -- the
 // entries between two survivors' landing points all move by the same amount, so a 64-entry chunk is a read, an add and a write
 // (the first form recomputed every entry's shift from ballots over the survivors: ~75 instructions per chunk).
+// front / ub (optional): the caller's "everything below `front` is expanded, except at most `ub` entries" (SearchRoarGraph kernel, select):
+// survivors that land below the front move it up and are counted.
 __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m_, uint32_t L_, uint32_t &psize,
-                                                 uint32_t &cur, int lane, const TagProtect tp = TagProtect()) {
+                                                 uint32_t &cur, int lane, const TagProtect tp = TagProtect(), uint32_t *front = nullptr,
+                                                 uint32_t *ub = nullptr) {
     const u64 FLAG = 1ull;
     // Everything that steers a loop or a branch here is the same in every lane; said so explicitly (readfirstlane), it lives in scalar
     // registers and the loops are scalar loops -- left to the compiler's divergence analysis, pool sizes that passed through LDS or
@@ -314,6 +317,12 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
     const u64 vm = __ballot(valid);
     if (vm == 0) return;
     const uint32_t s = (uint32_t)__popcll(vm);
+    if (front) {
+        const uint32_t below = (uint32_t)__popcll(__ballot(valid & (lo < *front)));
+        const uint32_t nf = *front + below;
+        *front = nf < L ? nf : L;
+        *ub += below;
+    }
     // Shift, top segment first: the entries from the rank-t survivor's lower bound up to the next survivor's (the pool's end for the
     // last one) move up by t + 1.  64-entry chunks, top chunk first, up to four chunks read before the first is written back: the LDS
     // executes a wave's instructions in order, a lower chunk's reads never overlap an upper chunk's (higher) write range, and a lower

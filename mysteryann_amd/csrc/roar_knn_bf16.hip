@@ -368,8 +368,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WP
         d.lb = __builtin_amdgcn_readfirstlane(lds_addr(bufs + (size_t)b * JT * NT + wave * 64));
         d.ln = lds_addr(nrm + b * 64);
         d.fast = near && t0 + BT <= p.count;
-        d.tb = reinterpret_cast<const unsigned char *>(p.bb + (p.first + t0 * p.stride) * KQ);
-        d.nb = reinterpret_cast<const unsigned char *>(p.bnorm + (p.first + t0 * p.stride));
+        // (uniform, and SAID so: the LDS-DMA takes its base from scalar registers, and the register allocator has been seen to keep such a
+        // pointer in vector registers and hand them to the instruction)
+        auto uniform_ptr = [](const void *q) {
+            const u64 v = (u64)q;
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            return reinterpret_cast<const unsigned char *>(((u64)hi << 32) | (u64)lo);  // (readfirstlane returns an int: no sign extension)
+        };
+        d.tb = uniform_ptr(p.bb + (p.first + t0 * p.stride) * KQ);
+        d.nb = uniform_ptr(p.bnorm + (p.first + t0 * p.stride));
         return d;
     };
     auto dma_one = [&](const DmaTile &d, int j) {  // j < JT: quads; j == JT: the rows' squared norms
@@ -452,7 +459,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WP
                     lds_write_b64(lds_addr(skey + at), ((u64)__float_as_uint(dist) << 32) | row);
                     lds_write_b16(lds_addr(sql + at), ql);
                 } else {  // the staging block is full (the first pass admits every row): straight to the list
-                    const uint32_t qi = q0 + ql;
+                    uint32_t q0v = q0;
+                    asm volatile("" : "+v"(q0v));  // (worked out HERE: hoisted out of the loop -- as the compiler did since round 4 -- the sixteen list addresses of this rare path are 32 registers, spilled, and the 512-d bucket reloaded some inside the loop)
+                    const uint32_t qi = q0v + ql;
                     const float hi = dist + knn_eps(p.ea[qi], p.kq[qi], bn, p.kappa, IP ? 1 : 0);
                     const uint32_t pos = atomicAdd(&p.cursor[qi], 1u);
                     if (pos < p.cap) p.cand[(u64)qi * p.cap + pos] = ((u64)f2ord_b(hi) << 32) | row;

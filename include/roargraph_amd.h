@@ -361,7 +361,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  * here L_pq is an argument and the remaining knobs are integers:
  *   "visited_mode"   ROAR_VISITED_EXACT | ROAR_VISITED_LDS | ROAR_VISITED_LDS_FORGETFUL | ROAR_VISITED_AUTO (default AUTO)
  *   "waves_per_cu"   resident single-wave workgroups per CU to launch (0 = auto: what registers and LDS allow)
- *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k or 3 * 2^k)
+ *   "vis_entries"    LDS visited-table entries per query (0 = auto from L_pq and the graph; 2^k, 3 * 2^k or 5 * 2^k)
  *   "max_grid"       cap on the number of resident workgroups launched (0 = no cap)
  *   "edge_floats"    0 auto | 1 off: inner product over rows whose screening codes fill whole 128-byte lines (128-d, 512-d): the scale
  *                    and bounds of every neighbour's screening row are kept beside the adjacency (8 bytes per edge, made on first

@@ -113,7 +113,7 @@ struct RoarSearchParams {
     uint32_t *stamp;
     uint32_t cell_prev, cell_stamp;
     // visited, LDS mode: sets (power of two) x 4 ways of u16 tags
-    uint32_t vis_sets_log2;  // search kernel only: bit 31: the table has 3 << (value & 31) sets; bit 30: forgetful form (a
+    uint32_t vis_sets_log2;  // search kernel only: bit 31: the table has 3 << (value & 31) sets (bit 28: 5 << ...); bit 30: forgetful form (a
                              // full set overwrites a victim; else ids that find their set full go to the spill list below);
                              // bit 29 (forgetful form, LDS pool): bit 15 of a tag = "its node is in the pool", never the victim
     // host-buffer form with a pageable query block: rows [0, *ready) of `queries` (pinned staging) have been written by the

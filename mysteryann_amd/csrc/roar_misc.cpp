@@ -206,8 +206,9 @@ int roar_set_option(roar_index *idx, const char *key, int64_t value) {
     } else if (k == "vis_entries") {
         {
             int64_t v = value;
-            while (v > 3 && !(v & 1)) v >>= 1;
-            if (value < 0 || (value > 0 && v != 1 && v != 2 && v != 3)) return fail(ROAR_ERR_ARG, "vis_entries must be 0, 2^k or 3 * 2^k");
+            while (v > 5 && !(v & 1)) v >>= 1;
+            if (value < 0 || (value > 0 && v != 1 && v != 2 && v != 3 && v != 4 && v != 5))
+                return fail(ROAR_ERR_ARG, "vis_entries must be 0, 2^k, 3 * 2^k or 5 * 2^k");
         }
         idx->vis_entries = (int)value;
     } else if (k == "tag_protect") {

@@ -111,7 +111,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // workgroups).
     uint32_t sets_log2 = 0;
     uint32_t entries = 0;
-    bool sets3 = false;
+    uint32_t smult = 1;  // sets = smult << sets_log2
     if (mode == ROAR_VISITED_LDS) {
         uint32_t want = (p.screen || idx->dim_pad * 4u < 768u) ? 4096u : 8192u;
         if (pick && pick->entries > 0 && !idx->building && !bipartite) want = pick->entries;
@@ -119,16 +119,20 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
         uint32_t min_sets = (uint32_t)((idx->n + 65533) / 65534);
         uint32_t sets = std::max(std::max(want / 4, min_sets), 16u);
         while ((1u << sets_log2) < sets) sets_log2++;
-        // 3 * 2^k sets (12 288, 24 576 ... tags) where that is what was asked for: the search kernel only
-        if (!bipartite && sets_log2 >= 2 && sets <= (3u << (sets_log2 - 2)) && (3u << (sets_log2 - 2)) >= min_sets) {
+        // 5 * 2^k and 3 * 2^k sets (1 280, 1 536, 2 560, 3 072 ... tags) where that is what was asked for: the search kernel only.  The
+        // smallest of 5/8, 3/4 and 1 times the power of two that holds what was asked for.
+        if (!bipartite && sets_log2 >= 3 && sets <= (5u << (sets_log2 - 3)) && (5u << (sets_log2 - 3)) >= min_sets) {
+            sets_log2 -= 3;
+            smult = 5;
+        } else if (!bipartite && sets_log2 >= 2 && sets <= (3u << (sets_log2 - 2)) && (3u << (sets_log2 - 2)) >= min_sets) {
             sets_log2 -= 2;
-            sets3 = true;
+            smult = 3;
         }
-        entries = (sets3 ? 12u : 4u) << sets_log2;
+        entries = (4u * smult) << sets_log2;
         if ((uint64_t)entries * 2 > 128 * 1024)
             return fail(ROAR_ERR_ARG, "visited table of %u entries does not fit in LDS", entries);
     }
-    p.vis_sets_log2 = sets_log2 | (sets3 ? 0x80000000u : 0u);  // (+ bit 30 once the spill lists are known to fit, below)
+    p.vis_sets_log2 = sets_log2 | (smult == 3 ? 0x80000000u : 0u) | (smult == 5 ? 0x10000000u : 0u);  // (+ bit 30 once the spill lists are known to fit, below)
     uint32_t off = 0;
     p.off_pool = off;
     off += round_up(8 * (L + 1), 16);
@@ -137,10 +141,20 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (the LDS is handed out in 1 280-byte blocks, below), and long pools live on resident workgroups: T2I-10M, L_pq = 1 000, 2 048 tags,
     // nine per CU 36.2 ms -> ten per CU (profiles/r04_long_pools_lds.txt).
     const uint32_t trip = (use_hub || bipartite || idx->adj_stride > 128u) ? 192u : idx->adj_stride > 64u ? 128u : 64u;
+    // One wave per query (never the multi-wave or the bipartite forms: their waves append to ck while others still read cid): the ids sit
+    // in the UPPER HALF of the keys' block.  A scoring pass reads its ids before it writes its keys (one wave: LDS operations in program
+    // order), the keys of the c rows scored so far end at byte 8 c, the ids not yet scored start at byte 4 trip + 4 c >= 8 c for every
+    // c <= trip.  512 bytes less per query at two chunks per row: with the 1 280-tag table (below) a 12th workgroup per CU at L_pq = 1 000.
+    const bool maybe_multiwave = !stream && !idx->building && (idx->search_kernel >= 2 || (idx->search_kernel == 0 && dense && nq <= (uint64_t)idx->n_cus));
+    const bool alias_ids = !bipartite && !use_hub && !maybe_multiwave && !idx->building;
     p.off_ck = off;
     off += bp_wg ? 8 * 64 * 8 : 8 * trip;   // eight waves x 64 keys in the workgroup form; else one adjacency round trip
-    p.off_cid = off;
-    off += bp_wg ? 4 * 64 * 8 : 4 * trip;
+    if (alias_ids) {
+        p.off_cid = p.off_ck + 4 * trip;
+    } else {
+        p.off_cid = off;
+        off += bp_wg ? 4 * 64 * 8 : 4 * trip;
+    }
     p.off_q = off;
     off += round_up(4 * idx->dim_pad, 16);
     if (p.screen) off += round_up(idx->dim_pad, 16);  // the query's 8-bit codes (screen8i_pass)
@@ -317,7 +331,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     sel.protect = 0;
     if (mode == ROAR_VISITED_LDS && forget && !bipartite && sel.form == ROAR_FORM_SEARCH && !sel.regpool && sel.waves == 1 && !sel.hub &&
         want_protect) {
-        const uint64_t sets = (uint64_t)(sets3 ? 3u : 1u) << sets_log2;
+        const uint64_t sets = (uint64_t)smult << sets_log2;
         if (idx->n > 0 && (idx->n - 1) / sets + 1 < 32768u) {
             p.vis_sets_log2 |= 0x20000000u;
             sel.protect = 1;
@@ -552,6 +566,15 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
                     const uint32_t e0 = b->entries;
                     try_pick(sc, ROAR_VISITED_LDS, e0 + e0 / 2);
                     if (!hard_error && (e0 & (e0 - 1)) == 0) try_pick(sc, ROAR_VISITED_LDS, e0 - e0 / 4);
+                    // the 5 * 2^k sizes on both sides of the winner (1 280 between 1 024 and 1 536 ...): at a long pool 256 tags are a workgroup per CU
+                    b = best_of();
+                    if (!hard_error && b && b->mode == ROAR_VISITED_LDS) {
+                        const uint32_t eb = b->entries;
+                        uint32_t lo5 = 640;
+                        while (lo5 * 2 < eb) lo5 *= 2;  // the largest 5 * 2^k below the winner; twice that is the smallest above it
+                        if (lo5 >= 1024) try_pick(sc, ROAR_VISITED_LDS, lo5);
+                        if (!hard_error && lo5 * 2 != eb && lo5 * 2 <= 5120) try_pick(sc, ROAR_VISITED_LDS, lo5 * 2);
+                    }
                 }
             }
         }

@@ -68,7 +68,7 @@ __device__ __forceinline__ RoarKArgs kargs() {
 //     ever stored to HBM (a one-word mark costs as much as 2-3.5 lines of a row gather, scripts/probe_cost.hip).
 template <int NC>
 __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32_t (&nb)[NC], uint16_t *vis, uint32_t sets_mask,
-                                             uint32_t sets_log2, bool three, bool forget, bool protect, bool (&fresh)[NC]) {
+                                             uint32_t sets_log2, uint32_t mult, bool forget, bool protect, bool (&fresh)[NC]) {
     const uint32_t tmask2 = protect ? 0x7FFF7FFFu : 0xFFFFFFFFu;  // (protect: bit 15 of a tag = "its node is in the pool", roar_wave.h TagProtect)
     uint32_t *w[NC];
     uint32_t tag[NC], x[NC], y[NC];
@@ -78,10 +78,14 @@ __device__ __forceinline__ void visited_ldsn(const bool (&isn)[NC], const uint32
     for (int c = 0; c < NC; ++c) {
         uint32_t set = nb[c] & sets_mask;
         uint32_t hi = nb[c] >> sets_log2;
-        if (three) {  // 3 << sets_log2 sets: set = id mod sets, tag = id div sets (exact division by 3 of a 32-bit value)
+        if (mult == 3u) {  // 3 << sets_log2 sets: set = id mod sets, tag = id div sets (exact division by 3 of a 32-bit value)
             const uint32_t q3 = __umulhi(hi, 0xAAAAAAABu) >> 1;
             set |= (hi - 3u * q3) << sets_log2;
             hi = q3;
+        } else if (mult == 5u) {  // 5 << sets_log2 sets (round 5: the size between 2^k and 3 * 2^(k-1) that leaves a long pool one more workgroup per CU)
+            const uint32_t q5 = __umulhi(hi, 0xCCCCCCCDu) >> 2;
+            set |= (hi - 5u * q5) << sets_log2;
+            hi = q5;
         }
         tag[c] = hi + 1u;
         w[c] = reinterpret_cast<uint32_t *>(vis + 4 * set);
@@ -951,7 +955,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
     const uint32_t AS = HUB ? p.hub_stride : p.adj_stride;
     const uint32_t L = p.L;
     const uint32_t sets_log2 = p.vis_sets_log2 & 31u;  // bit 31: three times that many sets; bit 30: forgetful form; bit 29: see `protect`
-    const bool sets3 = (p.vis_sets_log2 >> 31) != 0;
+    const uint32_t smult = (p.vis_sets_log2 >> 31) ? 3u : ((p.vis_sets_log2 >> 28) & 1u) ? 5u : 1u;  // (bit 28: five times that many sets)
     const bool forget = ((p.vis_sets_log2 >> 30) & 1u) != 0;
     const bool protect = PROT && !RP && forget && ((p.vis_sets_log2 >> 29) & 1u) != 0;  // bit 29: tags carry a "node is in the pool" bit
     // (exact LDS form: the workgroup's spill list -- u16 epoch tags in HBM -- has its epoch in LDS, ctrl[6])
@@ -1041,7 +1045,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 *reinterpret_cast<float4 *>(lq + i) = *reinterpret_cast<const float4 *>(qp + i);
         }
         if (MODE == VIS_LDS) {  // fresh visited table
-            const uint32_t n16 = ((sets3 ? 12u : 4u) << sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
+            const uint32_t n16 = ((4u * smult) << sets_log2) >> 3;  // sets * 4 ways * 2 B / 16 B
             for (uint32_t i = threadIdx.x; i < n16; i += 64 * W) reinterpret_cast<uint4 *>(vis)[i] = make_uint4(0, 0, 0, 0);
         }
         if (HUB)
@@ -1283,7 +1287,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                                 if (fresh[c]) __builtin_nontemporal_store((uint8_t)epoch, tags + nb[c]);
                             }
                         } else {
-                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, sets3, forget, protect, fresh);
+                            visited_ldsn<NC>(isn, nb, vis, sets_mask, sets_log2, smult, forget, protect, fresh);
                         }
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
@@ -1406,7 +1410,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     if constexpr (RP) merge_regpool(pk, psize, ck + b, cnt, L, pool, lane);
                     else {
                         TagProtect tp;
-                        if (MODE == VIS_LDS && protect) tp.vis = vis, tp.sets_mask = sets_mask, tp.sets_log2 = sets_log2, tp.three = sets3;
+                        if (MODE == VIS_LDS && protect) tp.vis = vis, tp.sets_mask = sets_mask, tp.sets_log2 = sets_log2, tp.mult = smult;
                         merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp, &front, &ub);
                     }
                 }

@@ -431,7 +431,7 @@ int roar_search_stream_info(roar_stream *s, const char *key, int64_t *value) {
     } else if (k == "ring") *value = s->ring;
     else if (k == "lds_bytes") *value = s->planned ? (int64_t)s->plan.p.lds_bytes : 0;
     else if (k == "screen") *value = s->planned && s->plan.p.screen ? 1 : 0;
-    else if (k == "vis_entries") *value = s->planned ? (int64_t)(((s->plan.p.vis_sets_log2 >> 31) ? 12u : 4u) << (s->plan.p.vis_sets_log2 & 31u)) : 0;
+    else if (k == "vis_entries") *value = s->planned ? (int64_t)(((s->plan.p.vis_sets_log2 >> 31) ? 12u : ((s->plan.p.vis_sets_log2 >> 28) & 1u) ? 20u : 4u) << (s->plan.p.vis_sets_log2 & 31u)) : 0;
     else if (k == "tag_protect") *value = s->planned ? s->plan.sel.protect : 0;
     else if (k == "register_pool") *value = s->planned ? s->plan.sel.regpool : 0;
     else if (k == "wall_clock_khz") *value = s->wall_khz;

@@ -222,14 +222,18 @@ __device__ __forceinline__ void score_candidates(const float *__restrict__ base,
 struct TagProtect {
     uint16_t *vis = nullptr;
     uint32_t sets_mask = 0, sets_log2 = 0;
-    bool three = false;
+    uint32_t mult = 1;  // sets = mult << sets_log2 (1, 3 or 5)
 };
 __device__ __forceinline__ void tag_protect(const TagProtect &tp, uint32_t id, bool on) {
     uint32_t set = id & tp.sets_mask, hi = id >> tp.sets_log2;
-    if (tp.three) {
+    if (tp.mult == 3u) {
         const uint32_t q3 = __umulhi(hi, 0xAAAAAAABu) >> 1;
         set |= (hi - 3u * q3) << tp.sets_log2;
         hi = q3;
+    } else if (tp.mult == 5u) {
+        const uint32_t q5 = __umulhi(hi, 0xCCCCCCCDu) >> 2;
+        set |= (hi - 5u * q5) << tp.sets_log2;
+        hi = q5;
     }
     const uint32_t tag = hi + 1u;
     uint32_t *w = reinterpret_cast<uint32_t *>(tp.vis + 4 * set);

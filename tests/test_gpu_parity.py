@@ -309,9 +309,10 @@ def torch_pad(q, dpad):
 
 
 def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
-    """The on-chip table also comes in 3 * 2^k sets (12 288 tags is the default for medium pools on a sparse graph): set =
-    id mod sets, tag = id div sets must stay a bijection -- a hit may never be false.  Tiny tables (96, 192 tags: they forget
-    all the time), the default-sized one, and an id range that makes the quotient of the division by 3 non-trivial."""
+    """The on-chip table also comes in 3 * 2^k and (round 5) 5 * 2^k sets (12 288 tags is the default for medium pools on a sparse
+    graph; 1 280 is what leaves a 1 000-entry pool a twelfth workgroup per CU): set = id mod sets, tag = id div sets must stay a
+    bijection -- a hit may never be false.  Tiny tables (80, 96, 160, 192 tags: full all the time), the default-sized ones, and an id
+    range that makes the quotient of the division by 3 / by 5 non-trivial."""
     import oracle
     from mysteryann_amd import index as mi
 
@@ -324,7 +325,7 @@ def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
     idx.set_option("hub_mode", 1)
     for L in (40, 150, 400):
         o = oracle.search_batch(base, off, nbrs, 3, q, K, L, 0)
-        for ve in (96, 192, 3072, 12288, 0):
+        for ve in (80, 96, 160, 192, 1280, 3072, 5120, 12288, 0):
             idx.set_option("vis_entries", ve)
             r = idx.SearchRoarGraphBatch(q, K, L)
             if ve:
@@ -333,13 +334,13 @@ def test_tag_table_of_three_times_a_power_of_two_sets(built_lib):
             assert np.array_equal(r["dists"], o["dists"]), (L, ve)
             assert np.array_equal(r["hops"], o["hops"]), (L, ve)
             assert np.array_equal(r["cmps"], o["cmps"]), (L, ve)  # a full set spills, it does not forget
-    assert idx.info("last_vis_entries") in (2048, 4096, 8192, 16384)  # auto: one of the sizes the calibration tries
+    assert idx.info("last_vis_entries") in (1024, 1280, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 16384)  # auto: one of the sizes the calibration tries
     assert idx.info("last_plan_calibrated") == 1
     idx.set_option("calibrate", 0)
     idx.SearchRoarGraphBatch(q, K, 400)
     assert idx.info("last_vis_entries") == 4096 and idx.info("last_plan_calibrated") == 0  # default with rows under 768 bytes
     with pytest.raises(Exception):
-        idx.set_option("vis_entries", 5 * 1024)
+        idx.set_option("vis_entries", 7 * 1024)
     idx.close()
 
 
@@ -409,7 +410,7 @@ def test_pool_members_keep_their_tags_without_moving_results(built_lib):
                     continue
                 idx.set_option("screen", screen)
                 tot = {0: 0, 1: 0}
-                for ve in ((64, 192, 256) if L == 70 else (256, 768, 1024)):
+                for ve in ((64, 160, 192, 256) if L == 70 else (256, 320, 768, 1024)):
                     idx.set_option("vis_entries", ve)
                     for prot in (0, 1):
                         idx.set_option("tag_protect", prot)

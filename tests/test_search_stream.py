@@ -323,11 +323,11 @@ def test_an_idle_stream_holds_no_workgroups_and_restarts(built_lib):
             t, out = st.submit(qd)
             assert st.wait(t) == 0
             _check(out, o, 0, nq, ("idle", rep))
-            t_end = time.time() + 5.0
+            t_end = time.time() + 30.0  # (they leave within microseconds; the margin is for a box that is busy with something else)
             while st.info("workgroups_alive") and time.time() < t_end:
                 time.sleep(0.001)
-            assert st.info("workgroups_alive") == 0
-            assert st.info("launches") > launches
+            assert st.info("workgroups_alive") == 0, (rep, st.info("workgroups_alive"), st.info("launches"))
+            assert st.info("launches") > launches, (rep, st.info("launches"), launches)
             launches = st.info("launches")
             # another kernel gets the whole chip while the stream is open and idle
             x = idx.SearchRoarGraphBatchDevice(qd, K, L)

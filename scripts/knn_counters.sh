@@ -3,7 +3,7 @@
 # one block of 65 536 training queries x 10 M base rows (scripts/knn_profile.py), the LAST pass (all rows) of the second run.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r4/knn_counters
+O=$R/gpurun_out/${ROUND_TAG:-r4}/knn_counters
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp

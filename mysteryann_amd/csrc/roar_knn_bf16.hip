@@ -866,7 +866,9 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
     uint64_t stride = stride0;
     static const int debug = [] {
         const char *e = getenv("ROAR_KNN_DEBUG");
-        return e ? atoi(e) : 0;
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "roargraph_amd: ROAR_KNN_DEBUG=%d -- a TIMING experiment of the kNN pass kernel (scripts/knn_forms.sh): the lists this process returns are WRONG\n", v);
+        return v;
     }();
     static unsigned long long *prof_dev = [] {
         unsigned long long *d = nullptr;

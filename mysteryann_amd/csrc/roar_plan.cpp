@@ -489,6 +489,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         uint32_t entries;
         int mode, screen;
         int protect = -1;  // (-1: whatever the default rule gave; the last stage fixes it)
+        uint32_t grid = 0;  // workgroups of the timed launch (the sample is at least one residency: how many the plan keeps resident)
     };
     std::vector<Cand> tried;
     tried.reserve(16);
@@ -497,6 +498,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         pk.screen = screen, pk.mode = mode, pk.entries = entries, pk.protect = protect;
         Cand c{pk, -1.f, 0, 0, 0, protect};
         c.ms = time_pick(pk, &c.entries, &c.mode, &c.screen);
+        c.grid = (uint32_t)idx->last_grid;
         if (c.ms < 0.f) return nullptr;
         for (const Cand &o : tried)  // (a table below the minimum for this many points is planned as the minimum: the same launch)
             if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen && o.protect == c.protect) return nullptr;
@@ -628,15 +630,17 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         idx->last_used_tags = false;
     }
     if (!best) return ROAR_OK;
-    // Among the candidates within 0.5 % of the fastest (noise), the one that counts best wins: HBM tags return the reference's cmps
-    // exactly, a bigger on-chip table forgets less (cmps >= the reference's; ids / distances / hops never depend on any of this) --
-    // and, all else equal, the default plan.  (1.5 % until round 5: once the kernel-argument reads stopped costing a round trip per
-    // hop, the 8 192-tag table -- eight workgroups per CU instead of twelve -- came within 1.2 % of the 4 096-tag one on the sample
-    // and won the tie, and the batch stream, which lives on resident workgroups, ran 1.8 % slower for it.)
+    // Among the candidates within 0.5 % of the fastest (noise): HBM tags first (they return the reference's cmps exactly); among on-chip
+    // tables the one that keeps MORE WORKGROUPS RESIDENT, then the bigger one (it forgets less: cmps >= the reference's; ids / distances /
+    // hops never depend on any of this), then the default plan.  One launch at a time they are a tie by definition; launches in flight
+    // and the batch stream live on resident workgroups.  (Rounds 4-5 let the bigger table win the tie: once the kernel-argument reads
+    // stopped costing a round trip per hop, the 8 192-tag table -- eight workgroups per CU instead of twelve -- came within 0.3-1.2 % of
+    // the 4 096-tag one on the sample in some runs, and the batch stream of those runs was 3 % slower: 7.15 against 7.39 M QPS.)
     {
         const float lim = best->ms * 1.005f;
         auto fidelity = [&](const Cand &c) -> uint64_t {
-            return ((uint64_t)(c.mode == ROAR_VISITED_EXACT ? 1 : 0) << 40) | ((uint64_t)c.entries << 8) | (uint64_t)(&c == &tried.front() ? 1 : 0);
+            return ((uint64_t)(c.mode == ROAR_VISITED_EXACT ? 1 : 0) << 60) | ((uint64_t)(c.grid & 0xFFFFFu) << 36) | ((uint64_t)c.entries << 8) |
+                   (uint64_t)(&c == &tried.front() ? 1 : 0);
         };
         for (const Cand &c : tried)
             if (c.ms <= lim && c.screen == best->screen && fidelity(c) > fidelity(*best)) best = &c;

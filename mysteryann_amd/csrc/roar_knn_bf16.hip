@@ -260,7 +260,8 @@ struct KnnBfParams {
 // matrix cores and the LDS were both the bound, and behind a per-tile barrier neither was ever busy all the time (0.39 of the bf16 peak,
 // profiles/r04_knn_kernel_stats.txt).  With 64 queries per wave a fragment feeds two MFMAs and the LDS runs at half its rate.
 //
-// Pipeline (one iteration = one tile of 64 base rows): a COUNTED wait -- s_waitcnt vmcnt((NBUF - 2)(JT + 1)): this thread's loads of the
+// Pipeline (round 4's, still the 512-d bucket's; up to 208-d an iteration is a PAIR of tiles now: TPB at the main loop).  One iteration =
+// one tile of 64 base rows: a COUNTED wait -- s_waitcnt vmcnt((NBUF - 2)(JT + 1)): this thread's loads of the
 // tile about to be read have landed, those of the NBUF - 2 tiles behind it stay in flight -- then a raw s_barrier (everybody's have, and
 // everybody has left the buffer read last), the loads of tile t + NBUF - 1 into that buffer, the MFMAs, the epilogue.  A
 // __syncthreads() would drain every load in flight (the compiler's fence waits vmcnt(0) for a pending LDS write), and one tile ahead

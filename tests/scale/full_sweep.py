@@ -19,7 +19,7 @@ ap.add_argument("--cpu-queries", type=int, default=2000)
 ap.add_argument("--out", default="gpurun_out/sweep_t2i10m.csv")
 ap.add_argument("--no-cpu", action="store_true")
 ap.add_argument("--builder", default="reference")
-ap.add_argument("--graph-cache", default="/tmp/r4_graph.index")
+ap.add_argument("--graph-cache", default="/tmp/roar_graph.index")
 args = ap.parse_args()
 n, d, nq, k = args.n, 200, 10_000, 10
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scripts"))

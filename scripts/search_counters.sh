@@ -4,7 +4,7 @@
 set -u
 L=${1:-1000}; T=${2:-2048}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r4/search_counters_L$L
+O=$R/gpurun_out/${ROUND_TAG:-r4}/search_counters_L$L
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp

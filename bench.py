@@ -569,6 +569,28 @@ def main():
                      scanned=torch.empty(rows, dtype=torch.int32, device=dev), short=torch.zeros(1, dtype=torch.int32, device=dev))
                 for _ in range(max(args.steps, args.warmup, 1))]
 
+    def poison(bufs):
+        """Result arrays that a timed loop is about to write: filled with values no search produces (ids -1 in every column, NaN
+        distances, hops -1), so that a step that wrote nothing -- a refused launch, a batch a stream never served -- cannot pass the
+        comparison with the per-launch results on what an EARLIER loop left in the same arrays."""
+        for o_ in bufs:
+            o_["ids"].fill_(-1), o_["dists"].fill_(float("nan")), o_["hops"].fill_(-1), o_["cmps"].fill_(-1), o_["short"].zero_()
+        torch.cuda.synchronize()
+
+    def steps_equal_outs(bufs, what, keys=("ids", "dists", "hops")):
+        """every timed step's results against the per-launch results of its batch (outs, made one launch at a time and checked against
+        ground truth above); a refused launch (0xFFFFFFFF in its short count) or any difference FAILS the run: a number measured over
+        steps that did not search is not a number."""
+        for s_ in range(args.steps):
+            if int(bufs[s_]["short"].item()) == -1:
+                raise RuntimeError(f"bench: {what}: the launch of step {s_} was refused (dirty launch cell): it did not search")
+            for key_ in keys:
+                a_, b_ = bufs[s_][key_], outs[s_ % B][key_]
+                same = bool((a_ == b_).all().item()) if key_ != "dists" else bool(torch.equal(a_, b_))
+                if not same:
+                    raise RuntimeError(f"bench: {what}: step {s_} wrote {key_} that differ from the per-launch results of batch {s_ % B}")
+        return True
+
     def timed_stream(order, bufs):
         """The same K steps through ONE batch stream (roar_search_stream_*): every step's batch is submitted and waited for inside the
         timed region; workgroups are not bound to a step -- they take queries from whatever has been submitted and cross step
@@ -585,6 +607,7 @@ def main():
             while st_.info("workgroups_alive") and time.time() < t_end:  # (the timed region starts from an idle stream)
                 time.sleep(0.0005)
             torch.cuda.synchronize()
+            poison(bufs)
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -623,6 +646,8 @@ def main():
         for s_ in range(args.warmup):
             run(chosen, order(s_), bufs[s_] if bufs else outs[order(s_)], streams[s_ % len(streams)])
         torch.cuda.synchronize()
+        if bufs:
+            poison(bufs)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -668,6 +693,8 @@ def main():
     idx.set_option("visited_mode", VIS[args.visited])
     wall_replay, gpu_replay = timed(lambda s_: 0)           # the same batch every step (rows of the last step still cached)
     wall_serial, gpu_ms = timed(lambda s_: s_ % B)          # distinct batches in rotation, one launch after the other:
+    if any(int(o_["short"].item()) == -1 for o_ in outs):   # (0xFFFFFFFF: a launch that found its cell dirty and did not search)
+        raise RuntimeError("bench: one launch at a time: a launch was refused (dirty launch cell): it did not search")
     last_kernel_ms = idx.info("last_kernel_ns") * 1e-6      #   the kernel's own duration (roofline) comes from this loop
     kernel_ms = gpu_ms / args.steps
     depth = len(side)
@@ -682,6 +709,7 @@ def main():
         sbufs = step_buffers(mine)
         wall, gpu_pipe = timed(lambda s_: s_ % B, depth, sbufs)
         idx.set_option("max_grid", 0)
+        steps_equal_outs(sbufs, f"{depth} launches in flight")
     else:
         wall, gpu_pipe = wall_serial, gpu_ms
         sbufs = step_buffers(mine)
@@ -692,9 +720,8 @@ def main():
     wall_stream = gpu_stream = None
     if not args.no_stream:
         wall_stream, gpu_stream, stream_info = timed_stream(lambda s_: s_ % B, sbufs)
-        stream_info["results_equal_per_launch_results"] = all(
-            bool((sbufs[s_]["ids"] == outs[s_ % B]["ids"]).all().item() and (sbufs[s_]["dists"] == outs[s_ % B]["dists"]).all().item()
-                 and (sbufs[s_]["hops"] == outs[s_ % B]["hops"]).all().item()) for s_ in range(args.steps))
+        # (the step buffers were poisoned inside timed_stream, after its warm-up: what is compared here was written by the timed steps)
+        stream_info["results_equal_per_launch_results"] = steps_equal_outs(sbufs, "batch stream")
         log(f"[rank {rank}] batch stream: {wall_stream * 1e3 / args.steps:.4f} ms per step (launches in flight: {wall_launches * 1e3 / args.steps:.4f}), "
             f"{stream_info}")
     use_stream = wall_stream is not None and wall_stream < wall_launches
@@ -731,13 +758,14 @@ def main():
         shbufs = step_buffers(sh)
         wall_s8, gpu_s8 = timed(lambda s_: s_ % B, depth, shbufs)
         idx.set_option("max_grid", 0)
+        steps_equal_outs(shbufs, "share of 8, launches in flight")
         wall_s8_1, _ = timed(lambda s_: s_ % B)
+        if any(int(o_["short"].item()) == -1 for o_ in outs):
+            raise RuntimeError("bench: share of 8, one launch at a time: a launch was refused (dirty launch cell)")
         wall_s8_stream = s8_info = None
         if not args.no_stream:
             wall_s8_stream, _, s8_info = timed_stream(lambda s_: s_ % B, shbufs)
-            s8_info["results_equal_per_launch_results"] = all(
-                bool((shbufs[s_]["ids"] == outs[s_ % B]["ids"]).all().item() and (shbufs[s_]["dists"] == outs[s_ % B]["dists"]).all().item())
-                for s_ in range(args.steps))
+            s8_info["results_equal_per_launch_results"] = steps_equal_outs(shbufs, "share of 8, batch stream")
         batches, outs = keep_b, keep_o
         share8 = share_of_8_block(args.nq, args.steps, wall_s8, wall_s8_1, depth, share_grid if depth > 1 else 0, qps, wall_s8_stream, s8_info)
 

@@ -201,23 +201,32 @@ int roar_search_batch_device(roar_index *idx, const float *queries_dev, uint64_t
  * cmps as with visited_mode LDS_FORGETFUL: >= the reference's).
  *   open    k, L_pq for every batch of the stream.  visited_mode must be AUTO or LDS_FORGETFUL (workgroups of several launches live
  *           side by side: nothing may be indexed by workgroup in HBM); the launch plan (screen, table size) is what the index's
- *           calibration measured for the largest batches at this L_pq -- measured on the first batch if it has not been yet.
+ *           calibration measured for the largest batches at this L_pq -- measured on the first batch if it has not been yet, PROVIDED
+ *           that batch is a sample one can measure on (at least 12 queries per compute unit: less than one residency of the chip
+ *           makes every table tie and lets noise pick).  A stream whose first batches are smaller runs on the default plan and
+ *           caches nothing; the first batch that is large enough (or a calibration made meanwhile by other launches of the index)
+ *           drains the stream once and plans it again (info keys "plan_provisional", "replans").  Results never depend on the plan.
  *   submit  as roar_search_batch_device without a stream argument: the batch must be COMPLETE in device memory when submit is called
  *           (synchronise whatever wrote it) and must stay valid and unchanged until its ticket has been waited for; the result
  *           arrays likewise.  At most 256 batches may be incomplete at a time (submit blocks on the oldest beyond that).  nq = 0:
  *           ticket 0, nothing to wait for.  Thread-safe; several host threads may submit to and wait on one stream.
  *   wait    blocks (polling pinned memory) until the batch is complete; *short_count (may be NULL) = queries of the batch that ended
  *           with fewer than k results (tail ids 0xFFFFFFFF).  Tickets may be waited for in any order, more than once, or never.
- *           A batch that does not complete within 60 s fails the stream (ROAR_ERR_DEVICE; every later call fails, close() returns
- *           the error and leaks the stream's buffers rather than free memory a kernel may still read).
+ *           (The stream's memory does not grow with the batches it has served: full per-ticket records are kept for the running epoch
+ *           of 65 536 batches and the one before it; of an older ticket only a non-zero short count is kept, its times() are gone.)
+ *           A batch that does not complete within 60 s fails the stream (ROAR_ERR_DEVICE; every later call fails).
  *   times   device wall clock (ns since an arbitrary origin) at which the batch's first query was taken and its last query finished.
- *   close   waits for every submitted batch and for the stream's launches to end, then frees the stream.
+ *   close   waits for every submitted batch and for the stream's launches to end, then frees the stream.  A FAILED stream: its launches
+ *           are given 10 s to end (a workgroup that waits for another gives up after 2 s on the device); if they did, the stream is
+ *           freed and the index released, and close() returns the error; if they did not, NOTHING is freed and the index stays
+ *           pinned -- roar_destroy / roar_set_base / a new graph keep refusing it, because they would free what those workgroups read.
  * While a stream is open the index's base rows and graph must not be replaced (those calls fail with ROAR_ERR_ARG), and other
  * searches on the same device share the chip with the stream's workgroups.
  * info keys: "launches" (kernel launches so far), "workgroups_launched", "workgroups_alive", "resident_capacity", "heals" (times
- * wait() found a batch pending and no workgroup alive), "epochs", "batches_submitted", "batches_completed", "ring", "lds_bytes",
+ * wait() found a batch pending and no workgroup alive), "epochs", "replans", "plan_provisional", "batches_submitted", "batches_completed", "ring", "lds_bytes",
  * "screen", "vis_entries", "tag_protect", "register_pool", "wall_clock_khz"; "take_calls" / "take_ns_total" / "busy_ns_total": calls of
- * the kernel's dequeue, device time all workgroups together spent in it / in the searches between (this epoch; one device read each). */
+ * the kernel's dequeue, device time all workgroups together spent in it / in the searches between (this epoch; one device read each);
+ * "debug_break" (tests): marks the stream failed, as a failed launch or a timed-out wait would. */
 typedef struct roar_stream roar_stream;
 int roar_search_stream_open(roar_index *idx, uint32_t k, uint32_t L_pq, roar_stream **out);
 int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t nq, uint32_t qstride_floats, uint32_t *ids_dev,

@@ -338,7 +338,11 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
 
 // The plan of a stream's workgroups (roar_stream.cpp): the batch-stream form of the kernel, with what the calibration measured for
 // the largest batches of this L_pq (measuring it now on `qdev` if need be); plan->grid = the workgroups the chip holds at once.
-int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan);
+int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
+                        bool *provisional);
+uint64_t plan_key(const roar_index *idx, uint64_t nq, uint32_t L);  // which cached calibration serves a launch like this one
+const roar_index::Calibration *find_calibration(const roar_index *idx, uint64_t key);
+uint64_t stream_calibration_min_queries(const roar_index *idx);  // a smaller sample cannot make the calibration of the largest batches
 
 // roar_launch.cpp
 int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st);

@@ -851,6 +851,7 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
     uint64_t ratio = cap / (4ull * k);
     if (ratio < 4) ratio = 4;
     if (ratio > 64) ratio = 64;
+#ifdef ROAR_KNN_EXPERIMENTS
     {
         static const int forced = [] {
             const char *e = getenv("ROAR_KNN_RATIO");
@@ -858,6 +859,7 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         }();
         if (forced >= 2) ratio = (uint64_t)forced;
     }
+#endif
     int P = 1;
     uint64_t stride0 = 1;
     while ((n + stride0 - 1) / stride0 > cap / 2) {
@@ -865,6 +867,10 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         ++P;
     }
     uint64_t stride = stride0;
+    // The timing experiments of scripts/knn_forms.sh (ROAR_KNN_DEBUG: nothing admitted, the lists come out WRONG; _RATIO, _SPLIT, _PROF, _TIME)
+    // exist only in a library built with -DROAR_KNN_EXPERIMENTS (scripts/build_variant.sh): the shipped library reads none of them, so
+    // a variable left exported cannot turn the builder's lists into a bad index.
+#ifdef ROAR_KNN_EXPERIMENTS
     static const int debug = [] {
         const char *e = getenv("ROAR_KNN_DEBUG");
         const int v = e ? atoi(e) : 0;
@@ -876,6 +882,10 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         if (getenv("ROAR_KNN_PROF") && hipMalloc((void **)&d, 64) == hipSuccess) (void)hipMemset(d, 0, 64);
         return d;
     }();
+#else
+    constexpr int debug = 0;
+    unsigned long long *const prof_dev = nullptr;
+#endif
     for (int pass = 0; pass < P; ++pass, stride /= ratio) {
         if ((e = hipMemsetAsync(cursor, 0, (size_t)nq * 4, st)) != hipSuccess) return (int)e;
         KnnBfParams p;
@@ -895,12 +905,17 @@ int roar_knn_run_bf16(const float *q, uint64_t ldq, uint32_t nq, const float *b,
         // the previous pass's, and the rest of the pass admits accordingly fewer rows: T2I-10M, k = 100, last pass: 3 060 rows per query in one
         // launch, 1 061 in four, 799 in eight -- and an admitting block is the expensive thing in the pass kernel (round 5,
         // profiles/r05_knn_forms.txt: 0.340 -> 0.281 s per 65 536-query block with everything of the round; 512-d 0.241 -> 0.186).
+#ifdef ROAR_KNN_EXPERIMENTS
         static const int split_env = [] {
             const char *e = getenv("ROAR_KNN_SPLIT");
             return e ? atoi(e) : 0;
         }();
+        const bool timed = pass == P - 1 && getenv("ROAR_KNN_TIME");  // the last pass alone, by the device's clock
+#else
+        constexpr int split_env = 0;
+        constexpr bool timed = false;
+#endif
         const uint64_t G = std::min<uint64_t>(split_env > 0 ? (uint64_t)split_env : 8, nslices);
-        const bool timed = pass == P - 1 && getenv("ROAR_KNN_TIME");  // debug: the last pass alone, by the device's clock
         static hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (timed) {
             if (!ev0) (void)hipEventCreate(&ev0), (void)hipEventCreate(&ev1);

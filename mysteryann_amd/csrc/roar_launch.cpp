@@ -76,7 +76,14 @@ int launch_planned(roar_index *idx, LaunchPlan &plan, hipStream_t st) {
     plan.p.cell_prev = seq / LAUNCH_RING;
     plan.p.cell_stamp = seq / LAUNCH_RING + 1u;
     int rc = roar_launch_search(&plan.p, &plan.sel, plan.grid, st);
-    if (rc != 0) return fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (rc != 0) {
+        // the launch that was to use the cell never ran: its stamp is rolled forward in stream order, as the kernel's last workgroup would
+        // have left it, or the cell would refuse its next user LAUNCH_RING launches from now (the cell itself is untouched: zero)
+        (void)hipGetLastError();
+        const int e = fail(ROAR_ERR_DEVICE, "search kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(const_cast<uint32_t *>(plan.p.stamp)), (int)plan.p.cell_stamp, 1, st) != hipSuccess) (void)hipGetLastError();
+        return e;
+    }
     return ROAR_OK;
 }
 }  // namespace roar_impl

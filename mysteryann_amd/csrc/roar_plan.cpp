@@ -665,6 +665,8 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
 
 // The plan of a launch: calibrated choices where there are any (measuring them now if `qdev` is given and this kind of launch
 // has not been seen yet), defaults otherwise.  *need_queries (may be null): set when a calibration is due but qdev is null.
+uint64_t stream_calibration_min_queries(const roar_index *idx) { return (uint64_t)std::max(idx->n_cus, 1) * 12u; }
+
 int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
                  bool *need_queries) {
     if (need_queries) *need_queries = false;
@@ -677,7 +679,7 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
     if (const roar_index::Calibration *c = find_calibration(idx, key)) {
         pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
         idx->last_calibrated = 1;
-    } else if (idx->max_grid > 0 && nq < (uint64_t)std::max(idx->n_cus, 1) * 12u) {
+    } else if (idx->max_grid > 0 && nq < stream_calibration_min_queries(idx)) {
         // a launch under a grid cap takes the calibration of the largest batches (plan_key) -- which a sample of less than one
         // residency of the chip cannot make: defaults for this call, nothing cached
     } else if (qdev) {
@@ -692,9 +694,13 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
     return plan_search(idx, nq, k, L, plan, false, &pick);
 }
 
-int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan) {
+// *provisional (may be null): set when the plan stands on defaults only because this batch is too small a sample to measure on -- the
+// stream asks again when a larger batch arrives (roar_stream.cpp).
+int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
+                        bool *provisional) {
     PlanPick pick;
     idx->last_calibrated = 0;
+    if (provisional) *provisional = false;
     const bool sane = idx->base && idx->adj && idx->gn == idx->n && L != 0 && k != 0 && k <= L;  // (else: plan_search words the error)
     if (sane && calibratable(idx)) {
         // A stream's workgroups share the chip with each other whatever the size of the batches: the regime of the largest batches,
@@ -706,6 +712,11 @@ int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_
         if (const roar_index::Calibration *c = find_calibration(idx, key)) {
             pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
             idx->last_calibrated = 1;
+        } else if (nq < stream_calibration_min_queries(idx)) {
+            // as resolve_plan does for a launch under a grid cap: a sample of less than one residency of the chip cannot make the calibration
+            // of the largest batches (every table ties, noise picks -- and the pick would be cached for every later stream and capped launch
+            // of this L_pq band): defaults for now, nothing cached
+            if (provisional) *provisional = true;
         } else if (qdev) {
             bool done = false;
             e = calibrate_plan(idx, qdev, nq, qstride, k, L, st, &pick, &done);

@@ -1503,9 +1503,11 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             const uint32_t nshort = atomicExch(cell + 2, 0u);
             if (o_short) *o_short = nshort;
             atomicExch(cell + 1, 0u);
-            atomicExch(KARG(stamp), KARG(cell_stamp));  // (this launch has finished with the cell)
-            __threadfence();
             atomicExch(cell, 0u);
+            // the stamp LAST, behind a fence: the cell's next user (LAUNCH_RING launches later, maybe on another stream) starts dequeuing as
+            // soon as it reads this launch's stamp, and must find every word of the cell zero by then
+            __threadfence();
+            atomicExch(KARG(stamp), KARG(cell_stamp));  // (this launch has finished with the cell)
         }
     }
 }

@@ -28,6 +28,8 @@
 // them.  Slots are reused every `ring` batches, only after the batch that held them is complete; a workgroup checks the slot's batch
 // number (seqlock) and treats a mismatch as "that batch was complete long ago".
 #include <chrono>
+#include <thread>
+#include <unordered_map>
 
 #include "roar_internal.h"
 
@@ -39,6 +41,7 @@ struct roar_stream {
     uint32_t ring = 256;   // slots (power of two): batches that may be incomplete at once
     uint32_t cap = 65536;  // batch numbers per epoch (counter cells)
     bool planned = false;
+    bool provisional = false;  // planned on defaults: no batch so far was large enough to calibrate on (submit() plans again when one is)
     LaunchPlan plan;
     uint32_t R = 0;  // workgroups the chip holds at once (plan.grid)
     // pinned host memory (one block) and its device address
@@ -57,8 +60,13 @@ struct roar_stream {
     uint64_t epoch_base = 0;  // ticket = epoch_base + batch number + 1
     uint64_t launched = 0;    // workgroups launched in this epoch
     std::vector<uint32_t> nq_of;      // per batch number of the epoch
-    std::vector<uint32_t> short_of;   // per ticket - 1, all epochs
-    std::vector<uint64_t> first_of, done_of;  // device wall clock per ticket - 1
+    // per-ticket records (short count, device wall clock of the first query taken / the batch complete), index ticket - 1 - rec_base: those
+    // of the running epoch and of the one before it.  When an epoch ends the older ones are dropped (a stream serves for days): of a
+    // dropped ticket only a NON-ZERO short count is kept (old_short: rare), so wait() answers for every ticket ever handed out.
+    std::vector<uint32_t> short_of;
+    std::vector<uint64_t> first_of, done_of;
+    uint64_t rec_base = 0;
+    std::unordered_map<uint64_t, uint32_t> old_short;
     struct Lane {
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
@@ -66,7 +74,7 @@ struct roar_stream {
     };
     std::vector<Lane> lanes;
     std::mutex mu;
-    int64_t n_launches = 0, n_heals = 0, n_resets = 0;
+    int64_t n_launches = 0, n_heals = 0, n_resets = 0, n_replans = 0;
     int wall_khz = 100000;
     bool broken = false;  // a launch failed or a wait timed out: every later call fails
 };
@@ -74,6 +82,7 @@ struct roar_stream {
 namespace {
 
 constexpr double WAIT_TIMEOUT_S = 60.0;
+constexpr double CLOSE_GRACE_S = 10.0;  // close() of a failed stream: how long its launches are given to end (device side: 2 s)
 
 size_t pin_bytes(const roar_stream *s) { return sizeof(RoarStreamCtl) + (size_t)s->ring * (sizeof(RoarStreamSlot) + sizeof(RoarStreamDone)); }
 
@@ -146,7 +155,7 @@ void poll(roar_stream *s) {
         volatile RoarStreamDone *d = &s->done[b & (s->ring - 1)];
         if (d->seq1_done != b + 1u) break;
         std::atomic_thread_fence(std::memory_order_acquire);
-        const uint64_t t = s->epoch_base + b;
+        const uint64_t t = s->epoch_base + b - s->rec_base;
         s->short_of[t] = d->nshort;
         s->first_of[t] = d->t_first;
         s->done_of[t] = d->t_done;
@@ -217,6 +226,29 @@ int wait_for(roar_stream *s, std::unique_lock<std::mutex> &lk, Pred pred, const 
     }
 }
 
+// the plan of the stream's workgroups, on this batch's own queries (a calibration, if one is due, runs ordinary launches here)
+int plan_stream(roar_stream *s, const float *queries_dev, uint64_t nq, uint32_t qstride_floats) {
+    roar_index *idx = s->idx;
+    hipStream_t st = idx->stream;
+    {
+        std::lock_guard<std::mutex> g2(idx->mu);
+        int e = resolve_stream_plan(idx, queries_dev, nq, qstride_floats, s->k, s->L, st, &s->plan, &s->provisional);
+        if (e) return e;
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    RoarSearchParams &p = s->plan.p;
+    p.s_ctl = reinterpret_cast<const RoarStreamCtl *>(s->pin_dev);
+    p.s_slots = reinterpret_cast<const RoarStreamSlot *>(s->pin_dev + sizeof(RoarStreamCtl));
+    p.s_done = reinterpret_cast<RoarStreamDone *>(s->pin_dev + sizeof(RoarStreamCtl) + (size_t)s->ring * sizeof(RoarStreamSlot));
+    p.s_cells = s->cells;
+    p.s_dev = s->dev;
+    p.s_ring = s->ring;
+    p.nq = 0;
+    s->R = std::max<uint32_t>(s->plan.grid, 1);
+    s->planned = true;
+    return ROAR_OK;
+}
+
 // every batch complete, every launch finished, counters zero: a new epoch of batch numbers
 int reset_epoch(roar_stream *s, std::unique_lock<std::mutex> &lk) {
     int e = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream");
@@ -228,6 +260,21 @@ int reset_epoch(roar_stream *s, std::unique_lock<std::mutex> &lk) {
     HIP_TRY(hipDeviceSynchronize());
     memset(s->pin, 0, pin_bytes(s));
     std::atomic_thread_fence(std::memory_order_seq_cst);
+    // the records of the epoch before the one that ends here go (tickets <= epoch_base: asked for again, wait() says so)
+    if (s->epoch_base > s->rec_base) {
+        const size_t drop = (size_t)(s->epoch_base - s->rec_base);
+        for (size_t i = 0; i < drop; ++i)
+            if (s->short_of[i] && s->old_short.size() < (1u << 20)) {
+                try {
+                    s->old_short[s->rec_base + i + 1] = s->short_of[i];
+                } catch (...) {
+                }
+            }
+        s->short_of.erase(s->short_of.begin(), s->short_of.begin() + drop);
+        s->first_of.erase(s->first_of.begin(), s->first_of.begin() + drop);
+        s->done_of.erase(s->done_of.begin(), s->done_of.begin() + drop);
+        s->rec_base = s->epoch_base;
+    }
     s->epoch_base += s->submitted;
     s->submitted = s->completed = s->claimed = 0;
     s->launched = 0;
@@ -314,23 +361,26 @@ int roar_search_stream_submit(roar_stream *s, const float *queries_dev, uint64_t
     int e = use_device(idx);
     if (e) return e;
     if (!s->planned) {
-        // the plan of the stream's workgroups, on the first batch's own queries (a calibration, if one is due, runs ordinary launches here)
-        hipStream_t st = idx->stream;
-        {
+        if ((e = plan_stream(s, queries_dev, nq, qstride_floats))) return e;
+    } else if (s->provisional) {
+        // The plan stands on defaults because no batch so far was a sample one can measure on (resolve_stream_plan).  This batch is, or
+        // somebody else's launches have made the calibration meanwhile: the stream is drained ONCE -- every batch complete, every launch
+        // over, so that the calibration's launches are timed on an idle chip -- and planned again.  Results do not depend on the plan.
+        bool due = nq >= stream_calibration_min_queries(idx);
+        if (!due) {
             std::lock_guard<std::mutex> g2(idx->mu);
-            if ((e = resolve_stream_plan(idx, queries_dev, nq, qstride_floats, s->k, s->L, st, &s->plan))) return e;
-            HIP_TRY(hipStreamSynchronize(st));
+            const int cap_keep = idx->max_grid;
+            idx->max_grid = 0x7FFFFFFF;  // (the key of the largest batches, as resolve_stream_plan makes it)
+            due = find_calibration(idx, plan_key(idx, nq, s->L)) != nullptr;
+            idx->max_grid = cap_keep;
         }
-        RoarSearchParams &p = s->plan.p;
-        p.s_ctl = reinterpret_cast<const RoarStreamCtl *>(s->pin_dev);
-        p.s_slots = reinterpret_cast<const RoarStreamSlot *>(s->pin_dev + sizeof(RoarStreamCtl));
-        p.s_done = reinterpret_cast<RoarStreamDone *>(s->pin_dev + sizeof(RoarStreamCtl) + (size_t)s->ring * sizeof(RoarStreamSlot));
-        p.s_cells = s->cells;
-        p.s_dev = s->dev;
-        p.s_ring = s->ring;
-        p.nq = 0;
-        s->R = std::max<uint32_t>(s->plan.grid, 1);
-        s->planned = true;
+        if (due) {
+            if ((e = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream"))) return e;
+            for (auto &c : s->lanes)
+                if (c.used) HIP_TRY(hipStreamSynchronize(c.st));
+            if ((e = plan_stream(s, queries_dev, nq, qstride_floats))) return e;
+            s->n_replans++;
+        }
     }
     if (s->submitted == s->cap && (e = reset_epoch(s, lk))) return e;
     // a slot is free once the batch that held it is complete
@@ -378,6 +428,14 @@ int roar_search_stream_wait(roar_stream *s, uint64_t ticket, uint32_t *short_cou
     if (ticket == 0) return ROAR_OK;
     std::unique_lock<std::mutex> lk(s->mu);
     if (ticket > s->epoch_base + s->submitted) return fail(ROAR_ERR_ARG, "search stream: ticket %llu was never handed out", (unsigned long long)ticket);
+    auto answer_old = [&]() {  // (complete when its epoch ended; its record was dropped one epoch later)
+        if (short_count) {
+            const auto it = s->old_short.find(ticket);
+            *short_count = it == s->old_short.end() ? 0u : it->second;
+        }
+        return ROAR_OK;
+    };
+    if (ticket <= s->rec_base) return answer_old();
     if (ticket > s->epoch_base) {  // (tickets of earlier epochs were complete when their epoch ended)
         if (s->broken) return fail(ROAR_ERR_DEVICE, "search stream: an earlier call failed; close the stream");
         int e = use_device(s->idx);
@@ -388,10 +446,11 @@ int roar_search_stream_wait(roar_stream *s, uint64_t ticket, uint32_t *short_cou
         if (s->epoch_base == epoch && b >= s->completed) {  // finished before an earlier batch: read its record directly
             volatile RoarStreamDone *d = &s->done[b & (s->ring - 1)];
             std::atomic_thread_fence(std::memory_order_acquire);
-            s->short_of[ticket - 1] = d->nshort, s->first_of[ticket - 1] = d->t_first, s->done_of[ticket - 1] = d->t_done;
+            s->short_of[ticket - 1 - s->rec_base] = d->nshort, s->first_of[ticket - 1 - s->rec_base] = d->t_first, s->done_of[ticket - 1 - s->rec_base] = d->t_done;
         }
     }
-    if (short_count) *short_count = s->short_of[ticket - 1];
+    if (ticket <= s->rec_base) return answer_old();  // (two epochs went by during the wait)
+    if (short_count) *short_count = s->short_of[ticket - 1 - s->rec_base];
     return ROAR_OK;
 }
 
@@ -399,18 +458,21 @@ int roar_search_stream_times(roar_stream *s, uint64_t ticket, uint64_t *first_ns
     if (!s || ticket == 0) return fail(ROAR_ERR_ARG, "bad arguments");
     std::lock_guard<std::mutex> guard(s->mu);
     if (ticket > s->epoch_base + s->submitted) return fail(ROAR_ERR_ARG, "search stream: ticket %llu was never handed out", (unsigned long long)ticket);
+    if (ticket <= s->rec_base)
+        return fail(ROAR_ERR_ARG, "search stream: the times of ticket %llu are no longer kept (they are for the running epoch of %u batches and the one before it)",
+                    (unsigned long long)ticket, s->cap);
     if (ticket > s->epoch_base) {
         poll(s);
         const uint32_t b = (uint32_t)(ticket - s->epoch_base - 1);
         if (!batch_done(s, b)) return fail(ROAR_ERR_ARG, "search stream: the batch is not complete yet (wait for it first)");
         if (b >= s->completed) {
             volatile RoarStreamDone *d = &s->done[b & (s->ring - 1)];
-            s->first_of[ticket - 1] = d->t_first, s->done_of[ticket - 1] = d->t_done;
+            s->first_of[ticket - 1 - s->rec_base] = d->t_first, s->done_of[ticket - 1 - s->rec_base] = d->t_done;
         }
     }
     const double ns_per_tick = 1.0e6 / (double)s->wall_khz;
-    if (first_ns) *first_ns = (uint64_t)((double)s->first_of[ticket - 1] * ns_per_tick);
-    if (done_ns) *done_ns = (uint64_t)((double)s->done_of[ticket - 1] * ns_per_tick);
+    if (first_ns) *first_ns = (uint64_t)((double)s->first_of[ticket - 1 - s->rec_base] * ns_per_tick);
+    if (done_ns) *done_ns = (uint64_t)((double)s->done_of[ticket - 1 - s->rec_base] * ns_per_tick);
     return ROAR_OK;
 }
 
@@ -423,7 +485,12 @@ int roar_search_stream_info(roar_stream *s, const char *key, int64_t *value) {
     else if (k == "workgroups_alive") *value = s->planned ? (int64_t)alive(s) : 0;
     else if (k == "resident_capacity") *value = s->R;
     else if (k == "heals") *value = s->n_heals;
-    else if (k == "epochs") *value = s->n_resets;
+    else if (k == "debug_break") {  // tests: the stream as a failed launch or a timed-out wait leaves it
+        s->broken = true;
+        *value = 1;
+    } else if (k == "epochs") *value = s->n_resets;
+    else if (k == "replans") *value = s->n_replans;
+    else if (k == "plan_provisional") *value = s->provisional ? 1 : 0;
     else if (k == "batches_submitted") *value = (int64_t)(s->epoch_base + s->submitted);
     else if (k == "batches_completed") {
         poll(s);
@@ -448,19 +515,47 @@ int roar_search_stream_close(roar_stream *s) {
     DeviceRestore keep_device_;
     if (!s) return ROAR_OK;
     int rc = ROAR_OK;
+    bool launches_over = true;  // every launch of the stream is known to have ended (cleanly or not): nothing reads its buffers or the index
     {
         std::unique_lock<std::mutex> lk(s->mu);
         (void)use_device(s->idx);
-        if (s->broken) rc = fail(ROAR_ERR_DEVICE, "search stream: an earlier call failed; the stream's buffers are not freed (workgroups may still be reading them)");
-        else if (s->planned) rc = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream");
-        if (rc == ROAR_OK) {
+        if (!s->broken && s->planned) rc = wait_for(s, lk, [&] { return s->completed == s->submitted; }, "the drain of the stream");
+        if (rc == ROAR_OK && !s->broken) {
             // every batch is complete: the workgroups find nothing published and leave; their launches end
             for (auto &c : s->lanes)
                 if (c.used && hipStreamSynchronize(c.st) != hipSuccess) rc = fail(ROAR_ERR_DEVICE, "search stream: a launch failed: %s", hipGetErrorString(hipGetLastError()));
+        } else {
+            // A stream that failed or did not drain: its workgroups are bounded on the device (one that waits for another gives up after
+            // STREAM_SPIN_LIMIT_TICKS = 2 s, the others finish the queries they hold), so their launches are given CLOSE_GRACE_S to end.
+            // Only then may anything they read be freed -- and only then is the index let go (roar_destroy / roar_set_base / a new graph
+            // would otherwise free base rows, adjacency and screening copy under running workgroups).
+            const std::string keep = g_err;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (auto &c : s->lanes) {
+                if (!c.used) continue;
+                for (;;) {
+                    const hipError_t q = hipEventQuery(c.ev);
+                    if (q != hipErrorNotReady) break;  // (ended; an error status is an ended launch too)
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > CLOSE_GRACE_S) {
+                        launches_over = false;
+                        break;
+                    }
+                    lk.unlock();
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                    lk.lock();
+                }
+                if (!launches_over) break;
+            }
+            (void)hipGetLastError();
+            g_err = keep;
+            if (rc == ROAR_OK)
+                rc = fail(ROAR_ERR_DEVICE, launches_over ? "search stream: an earlier call failed; the stream is closed, its results are not to be used"
+                                                         : "search stream: an earlier call failed and its workgroups are still running: the stream's buffers are "
+                                                           "not freed and the index stays pinned (roar_destroy will refuse it)");
         }
     }
+    if (!launches_over) return rc;  // (nothing freed, streams_open kept: the index must outlive workgroups that may still read it)
     s->idx->streams_open.fetch_sub(1);
-    if (rc != ROAR_OK) return rc;  // (a stream that did not drain keeps its memory: workgroups may still be reading it)
     for (auto &c : s->lanes) {
         (void)hipEventDestroy(c.ev);
         (void)hipStreamDestroy(c.st);
@@ -469,7 +564,7 @@ int roar_search_stream_close(roar_stream *s) {
     (void)hipFree(s->dev);
     (void)hipHostFree(s->pin);
     delete s;
-    return ROAR_OK;
+    return rc;
 }
 
 }  // extern "C"

@@ -490,6 +490,9 @@ def normalize(arr):
     return arr
 
 
+_LEAKED_BY_FAILED_STREAMS = []
+
+
 class SearchStream:
     """ctypes mirror of roar_search_stream_* (device buffers: torch tensors in HBM).  The tensors of a submitted batch are kept alive
     here until its ticket has been waited for."""
@@ -522,6 +525,10 @@ class SearchStream:
             C.c_void_p(out["hops"].data_ptr()), C.c_void_p(out["scanned"].data_ptr()), C.byref(t)))
         if t.value:
             self._keep[t.value] = (queries, out)
+            if len(self._keep) > 1024:  # tickets nobody waits for: their tensors are let go once the stream says their batches are complete
+                done = self.info("batches_completed")
+                for old in [x for x in self._keep if x <= done]:
+                    del self._keep[old]
         return t.value, out
 
     def wait(self, ticket):
@@ -544,7 +551,14 @@ class SearchStream:
     def close(self):
         if self._h is not None:
             h, self._h = self._h, None
-            capi.check(self._lib.roar_search_stream_close(h))
+            try:
+                capi.check(self._lib.roar_search_stream_close(h))
+            except capi.RoarError:
+                # a failed stream whose launches may still be running keeps its memory and pins the index (include/roargraph_amd.h):
+                # the tensors of its batches must outlive them too
+                _LEAKED_BY_FAILED_STREAMS.append((self._index, self._keep))
+                self._keep = {}
+                raise
             self._keep.clear()
 
     def __enter__(self):

@@ -11,7 +11,7 @@ pids=""
 for f in roar_kernels.hip roar_search_lds_ip.hip roar_search_lds_l2.hip roar_search_exact_ip.hip roar_search_exact_l2.hip roar_build.hip roar_rgbuild.hip roar_knn.hip roar_knn_bf16.hip roar_hub.hip; do
   /opt/rocm/bin/hipcc $flags -c $here/$f -o $tmp/${f%.hip}.o & pids="$pids $!"
 done
-for f in roar_capi.cpp roar_sharded.cpp; do
+for f in $(cd $here && ls roar_*.cpp); do
   /opt/rocm/bin/hipcc $flags -x hip -c $here/$f -o $tmp/${f%.cpp}.o & pids="$pids $!"
 done
 for p in $pids; do wait $p; done

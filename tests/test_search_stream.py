@@ -169,6 +169,44 @@ def test_slots_and_counter_cells_are_reused(built_lib, monkeypatch):
             assert st.wait(t) == 0  # (twice: harmless)
             _check(out, o, lo, hi, "ring")
         assert [t for t, *_ in pend] == list(range(1, 51))
+        # the stream's memory does not grow with the batches it has served: full records for the running epoch and the one before it
+        from mysteryann_amd.capi import ERR_ARG, RoarError
+
+        st.times(pend[-1][0])
+        with pytest.raises(RoarError) as e:
+            st.times(pend[0][0])
+        assert e.value.code == ERR_ARG and "no longer kept" in str(e.value)
+    idx.close()
+
+
+def test_short_counts_of_tickets_older_than_the_kept_records(built_lib, monkeypatch):
+    """wait() answers for every ticket ever handed out: of a ticket whose record was dropped (two epochs back) the non-zero short count
+    is still known."""
+    import torch
+
+    from mysteryann_amd import index as mi
+
+    monkeypatch.setenv("ROAR_STREAM_CAP", "4")
+    n, d = 200, 24
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((9, d)).astype(np.float32)
+    off = np.zeros(n + 1, np.uint64)
+    nb = []
+    for v in range(n):  # nodes 0..4: a closed clique, nothing else is reached from entry point 0 -> every query ends short of k = 10
+        row = [u for u in range(5) if u != v] if v < 5 else [0]
+        nb += row
+        off[v + 1] = len(nb)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(0, off, np.array(nb, np.uint32))
+    idx.set_option("calibrate", 0)
+    qd = torch.from_numpy(q).cuda()
+    with idx.OpenSearchStream(K, 20) as st:
+        tickets = [st.submit(qd[: 1 + (i % 9)])[0] for i in range(14)]
+        assert st.info("epochs") == 3
+        for i, t in enumerate(tickets):
+            assert st.wait(t) == 1 + (i % 9), (i, t)
     idx.close()
 
 
@@ -333,4 +371,85 @@ def test_an_idle_stream_holds_no_workgroups_and_restarts(built_lib):
             x = idx.SearchRoarGraphBatchDevice(qd, K, L)
             torch.cuda.synchronize()
             assert np.array_equal(x["ids"].cpu().numpy().view(np.uint32), o["ids"])
+    idx.close()
+
+
+def test_a_small_first_batch_does_not_make_the_calibration(built_lib):
+    """a stream whose first batch is smaller than one residency of the chip must not measure (and cache, for every later
+    stream and capped launch of this L_pq band) the launch plan of the largest batches on it: it runs on defaults ("plan_provisional"),
+    caches nothing, and plans again -- once, drained -- when a batch arrives that is a sample one can measure on.  Results are the
+    oracle's before and after."""
+    import oracle
+    import torch
+
+    from mysteryann_amd import index as mi
+
+    n, d, nq, L = 30000, 200, 4500, 40
+    base, q, off, nbrs = _random_case(n, d, nq, seed=33)
+    o = oracle.search_batch(base, off, nbrs, 5, q, K, L, 1, threads=8)
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(5, off, nbrs)  # (calibrate = 1, the default)
+    qd = torch.from_numpy(q).cuda()
+    need = idx.info("n_cus") * 12
+    assert nq >= need, (nq, need)
+    with idx.OpenSearchStream(K, L) as st:
+        t, out = st.submit(qd[:5])
+        assert st.wait(t) == 0
+        _check(out, o, 0, 5, "five queries")
+        assert st.info("plan_provisional") == 1 and idx.info("calibrations") == 0
+        t, out = st.submit(qd[5:105])
+        assert st.wait(t) == 0
+        _check(out, o, 5, 105, "a hundred queries")
+        assert st.info("plan_provisional") == 1 and idx.info("calibrations") == 0 and st.info("replans") == 0
+        pend = [(st.submit(qd[200:300]), 200, 300), (st.submit(qd), 0, nq), (st.submit(qd[100:200]), 100, 200)]  # the second one plans again
+        for (t, out), lo, hi in pend:
+            assert st.wait(t) == 0
+            _check(out, o, lo, hi, ("after the calibration", lo, hi))
+        assert st.info("plan_provisional") == 0 and st.info("replans") == 1 and idx.info("calibrations") >= 1
+    cals = idx.info("calibrations")
+    with idx.OpenSearchStream(K, L) as st:  # a second stream, small batches only: takes what was measured
+        t, out = st.submit(qd[:7])
+        assert st.wait(t) == 0
+        _check(out, o, 0, 7, "second stream")
+        assert st.info("plan_provisional") == 0 and idx.info("calibrations") == cals
+    idx.close()
+
+
+def test_closing_a_failed_stream_frees_it_once_its_launches_are_over(built_lib):
+    """close() of a failed stream may let the index go (roar_set_base / roar_destroy free what workgroups read) only when
+    the stream's launches are known to have ended; then it frees the stream as well and still returns the error."""
+    import torch
+
+    from mysteryann_amd import index as mi
+    from mysteryann_amd.capi import ERR_ARG, ERR_DEVICE, RoarError
+
+    n, d, nq, L = 3000, 128, 300, 30
+    base, q, off, nbrs = _random_case(n, d, nq, seed=5)
+    idx = mi.IndexBipartite(d, n, 0, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(1, off, nbrs)
+    idx.set_option("calibrate", 0)
+    qd = torch.from_numpy(q).cuda()
+    ref = idx.SearchRoarGraphBatchDevice(qd, K, L)
+    torch.cuda.synchronize()
+    st = idx.OpenSearchStream(K, L)
+    t, out = st.submit(qd)
+    assert st.wait(t) == 0
+    assert st.info("debug_break") == 1
+    with pytest.raises(RoarError) as e:
+        st.submit(qd)
+    assert e.value.code == ERR_DEVICE
+    with pytest.raises(RoarError) as e:  # (still open: the index is in use)
+        idx.SetBaseData(base)
+    assert e.value.code == ERR_ARG
+    with pytest.raises(RoarError) as e:
+        st.close()
+    assert e.value.code == ERR_DEVICE and "closed" in str(e.value)
+    idx.SetBaseData(base)  # the launches were over: the index is free again
+    idx.SetProjectionGraph(1, off, nbrs)
+    with idx.OpenSearchStream(K, L) as st2:
+        t, out2 = st2.submit(qd)
+        assert st2.wait(t) == 0
+        assert np.array_equal(out2["ids"].cpu().numpy(), ref["ids"].cpu().numpy())
     idx.close()

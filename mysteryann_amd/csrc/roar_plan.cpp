@@ -400,7 +400,11 @@ uint64_t plan_key(const roar_index *idx, uint64_t nq, uint32_t L) {
     // ... and by WHICH choices were free when the entry was measured: what is measured with an option fixed (screen forced on, the visited
     // form given, a table size given) is conditional on it and says nothing about the launch with that option back on AUTO
     const uint64_t fixed = (uint64_t)(idx->screen_mode & 3) | ((uint64_t)(idx->visited_mode & 3) << 2) | ((uint64_t)(idx->vis_entries & 0xFFFFF) << 4);
-    return (uint64_t)lband | ((uint64_t)band << 8) | ((uint64_t)(idx->waves_per_cu & 0xFF) << 20) | (fixed << 28);
+    // ... and by the REGIME the entry is for: a launch that has the chip to itself, or one that shares it (a grid cap, a stream's
+    // workgroups).  The candidates are timed the same way -- alone, on the whole chip -- but ranked differently (calibrate_plan: a
+    // shared chip lives on resident workgroups, and the timings of one launch at a time cannot see that)
+    const uint64_t shared = idx->max_grid > 0 ? 1u : 0u;
+    return (uint64_t)lband | ((uint64_t)band << 8) | ((uint64_t)(idx->waves_per_cu & 0xFF) << 20) | (fixed << 28) | (shared << 52);
 }
 
 const roar_index::Calibration *find_calibration(const roar_index *idx, uint64_t key) {
@@ -519,7 +523,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         if (default_ms >= 0.f) {
             PlanPick pk;
             pk.screen = su, pk.mode = mu, pk.entries = mu == ROAR_VISITED_LDS ? eu : 0;
-            tried.push_back(Cand{pk, default_ms, eu, mu, su, -1});
+            tried.push_back(Cand{pk, default_ms, eu, mu, su, -1, (uint32_t)idx->last_grid});
             if (log)
                 fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: default plan (screen %s, %s, %u tags): %.3f ms\n", L, S,
                         su ? "on" : "off", mu == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", eu, default_ms);
@@ -617,9 +621,16 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     (void)hipFree(sc_ids);
     idx->max_grid = cap_keep;
     if (hard_error) return hard_error;
+    // (a launch that shares the chip does not want the per-workgroup lists in HBM: launches that use them run one behind the other, and a
+    // stream cannot use them at all -- an on-chip table wins there whenever one ran)
+    const bool shared = cap_keep > 0;
+    bool any_table = false;
+    for (const Cand &c : tried) any_table = any_table || c.mode != ROAR_VISITED_EXACT;
     const Cand *best = nullptr;
-    for (const Cand &c : tried)
+    for (const Cand &c : tried) {
+        if (shared && any_table && c.mode == ROAR_VISITED_EXACT) continue;
         if (!best || c.ms < best->ms) best = &c;
+    }
     // the HBM tag lists (up to half of the free memory) were made for a candidate: unless it won, or they were there before, they go
     if (!had_tags && idx->tags && !(best && best->mode == ROAR_VISITED_EXACT)) {
         (void)hipFree(idx->tags);
@@ -636,14 +647,20 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     // and the batch stream live on resident workgroups.  (Rounds 4-5 let the bigger table win the tie: once the kernel-argument reads
     // stopped costing a round trip per hop, the 8 192-tag table -- eight workgroups per CU instead of twelve -- came within 0.3-1.2 % of
     // the 4 096-tag one on the sample in some runs, and the batch stream of those runs was 3 % slower: 7.15 against 7.39 M QPS.)
+    // A launch that SHARES the chip (grid cap, stream: plan_key's regime bit) widens the tie to 2 %: one launch at a time the tables from
+    // 2 048 to 8 192 tags are within +-1.5 % of each other on the benchmark graph, run to run, while through a stream the 8 192-tag table
+    // (eight workgroups per CU) is 3 % slower than the 4 096-tag one (twelve) for 10 000-query batches and 4.7 % slower for 1 250-query ones
+    // (profiles/r06_table_regime_probe.txt) -- the driver's round-5 run picked it on a 0.6 % "win" and lost 3 % of `value`.
     {
-        const float lim = best->ms * 1.005f;
+        const float lim = best->ms * (shared ? 1.02f : 1.005f);
         auto fidelity = [&](const Cand &c) -> uint64_t {
             return ((uint64_t)(c.mode == ROAR_VISITED_EXACT ? 1 : 0) << 60) | ((uint64_t)(c.grid & 0xFFFFFu) << 36) | ((uint64_t)c.entries << 8) |
                    (uint64_t)(&c == &tried.front() ? 1 : 0);
         };
-        for (const Cand &c : tried)
+        for (const Cand &c : tried) {
+            if (shared && any_table && c.mode == ROAR_VISITED_EXACT) continue;
             if (c.ms <= lim && c.screen == best->screen && fidelity(c) > fidelity(*best)) best = &c;
+        }
     }
     out->screen = screen_free ? best->screen : -1;
     out->mode = mode_free ? best->mode : -1;

@@ -1414,6 +1414,12 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp, &front, &ub);
                     }
                 }
+#ifdef ROAR_HOP_PAD
+                // measurement builds only (scripts/build_variant.sh -DROAR_HOP_PAD=n): the wave sits out n x 64 more cycles per hop where
+                // the merge is, issuing nothing -- the slope of the kernel time over the pad says how much of a hop's own time the
+                // launch's rate hangs on (profiles/r06_hop_pad_probe.txt)
+                __builtin_amdgcn_s_sleep(ROAR_HOP_PAD);
+#endif
                 if (PROF) t_merge += (long long)__builtin_readcyclecounter() - s0;
             }
         }

@@ -413,6 +413,12 @@ def test_a_small_first_batch_does_not_make_the_calibration(built_lib):
         assert st.wait(t) == 0
         _check(out, o, 0, 7, "second stream")
         assert st.info("plan_provisional") == 0 and idx.info("calibrations") == cals
+    # a launch that has the chip to itself is another regime: the same candidates ranked without the preference for resident workgroups,
+    # its own entry in the cache
+    r = idx.SearchRoarGraphBatchDevice(qd, K, L)
+    torch.cuda.synchronize()
+    assert idx.info("calibrations") == cals + 1
+    assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), o["ids"])
     idx.close()
 
 

@@ -1030,6 +1030,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
             }
         }
         long long tq0 = 0, t_adj = 0, t_filter = 0, t_score = 0, t_merge = 0, t_sel = 0;
+        [[maybe_unused]] long long t_mphase[3] = {0, 0, 0};  // inside the merge: lower bounds, ranks, shift (roar_wave.h merge_candidates)
         uint32_t pf_hit = 0, n_rt = 0, n_surv = 0;
         PassProf pprof;
         if (PROF) tq0 = (long long)__builtin_readcyclecounter();
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     else {
                         TagProtect tp;
                         if (MODE == VIS_LDS && protect) tp.vis = vis, tp.sets_mask = sets_mask, tp.sets_log2 = sets_log2, tp.mult = smult;
-                        merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp, &front, &ub);
+                        merge_candidates(pool, ck + b, cnt, L, psize, cur, lane, tp, &front, &ub, PROF ? t_mphase : nullptr);
                     }
                 }
 #ifdef ROAR_HOP_PAD
@@ -1478,7 +1479,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                     o[10] = (unsigned long long)pprof.tail;
                     o[11] = pprof.passes;
                     o[12] = n_surv;
-                    o[13] = o[14] = o[15] = 0;
+                    o[13] = (unsigned long long)t_mphase[0], o[14] = (unsigned long long)t_mphase[1], o[15] = (unsigned long long)t_mphase[2];
                 }
             }
             if constexpr (STREAM) {

@@ -251,18 +251,37 @@ __device__ __forceinline__ void tag_protect(const TagProtect &tp, uint32_t id, b
 // Sequential inserts keep the top-L of everything seen; so does this merge, entry for entry.
 // Duplicate (distance, id) pairs are dropped exactly as the binary-search probe does (:161-162).
 //
-// A hop of a long pool spends a third of its time here (T2I-10M, L_pq = 1 000: 6 000 of 17 500 cycles, profiles/r04_long_pools_phases.txt),
-// and that time is INSTRUCTIONS, not LDS latency: a wave-wide instruction costs its four cycles whether it moves one survivor or
-// sixty-four.  So: (1) the lower bounds start from 64 splitters read once (every (psize / 64)-th entry; a ballot per survivor names its
-// segment) and finish with log2(psize / 64) per-lane probes instead of log2(psize); (2) the pool is shifted SEGMENT by segment -- the
-// entries between two survivors' landing points all move by the same amount, so a 64-entry chunk is a read, an add and a write
-// (the first form recomputed every entry's shift from ballots over the survivors: ~75 instructions per chunk).
+// A hop of a long pool spends a third of its time here, and a launch of long pools is bound by its waves' own chains, not by the memory
+// system (round 6, profiles/r06_hop_pad_probe.txt: 4 096 idle cycles more per hop cost a 10 000-query launch at L_pq = 1 000 20 % --
+// 0.7 of what a purely latency-bound launch would pay).  That time is INSTRUCTIONS and dependent LDS round trips, not LDS bandwidth: a
+// wave-wide instruction costs its four cycles whether it moves one survivor or sixty-four.  Three steps, each a short chain:
+//   (1) lower bounds: 64 splitters read once (every (P / 64)-th entry; a ballot per survivor names its segment), then the segments
+//       THEMSELVES -- up to four survivors' segments side by side in one wave-wide read, a ballot of "entry < key" per group is the offset
+//       in the segment and a ballot of "entry == key" the reference's duplicate test: two dependent reads where rounds 4-5 made seven
+//       (five binary-search probes and the duplicate probe behind the splitters);
+//   (2) ranks among the survivors: one compare per survivor;
+//   (3) the shift, CHUNK by chunk from the top: 64-entry chunks on absolute 64-entry boundaries, eight read before the first is written
+//       back (the LDS executes a wave's instructions in order; a chunk's writes go to higher addresses than every chunk read after it).
+//       A chunk that no survivor lands in moves by one uniform amount; in a chunk with landing points a lane subtracts one per landing
+//       point above its entry.  (Rounds 4-5 shifted segment by segment between landing points: a read-wait-write per survivor for the
+//       segment's partial chunk on top of the whole chunks' -- 2 440 of the merge's 5 440 cycles per hop at L_pq = 1 000,
+//       profiles/r06_merge_phases.txt.)
 // front / ub (optional): the caller's "everything below `front` is expanded, except at most `ub` entries" (SearchRoarGraph kernel, select):
 // survivors that land below the front move it up and are counted.
 __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint32_t m_, uint32_t L_, uint32_t &psize,
                                                  uint32_t &cur, int lane, const TagProtect tp = TagProtect(), uint32_t *front = nullptr,
-                                                 uint32_t *ub = nullptr) {
+                                                 uint32_t *ub = nullptr, long long *mprof = nullptr) {
     const u64 FLAG = 1ull;
+    // (mprof, instrumented instantiation only: cycles of {the lower bounds, ranks and duplicates, the shift}; the rest of the caller's
+    // merge time is the keys' own stores and the tag protection)
+    long long mt0 = mprof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int i) {
+        if (mprof) {
+            const long long t = (long long)__builtin_readcyclecounter();
+            mprof[i] += t - mt0;
+            mt0 = t;
+        }
+    };
     // Everything that steers a loop or a branch here is the same in every lane; said so explicitly (readfirstlane), it lives in scalar
     // registers and the loops are scalar loops -- left to the compiler's divergence analysis, pool sizes that passed through LDS or
     // through per-lane arithmetic were vector values and every `if` below a save / mask / restore of EXEC.
@@ -276,7 +295,7 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
     }
     const u64 vm0 = __ballot(valid);
     if (vm0 == 0) return;
-    // lower bound of key among the (flag-masked) pool keys
+    // ---- (1) lower bound of key among the (flag-masked) pool keys, and "already in the pool"
     uint32_t lo = 0, len = P, span = P;  // (span: the longest range any lane still has to search)
     if (P > 128u) {
         // segment l = entries [l step, (l + 1) step) cut at P; its splitter = its last entry (segments past the end repeat the pool's last)
@@ -308,15 +327,26 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
         const u64 e = pool[lo < P ? lo : Pm1] & ~FLAG;
         valid = valid & !((lo < P) & (e == key));  // already in the pool
     }
-    // rank among the surviving candidates; a later lane with an equal key is a duplicate
+    lap(0);
+    // ---- (2) rank among the surviving candidates; a later lane with an equal key is a duplicate (never among the neighbours of one
+    // row -- their ids are distinct -- but among the bipartite variant's random entry points)
     uint32_t r = 0;
-    for (u64 it = __ballot(valid); it; it &= it - 1) {
-        const int j = __ffsll((long long)it) - 1;
-        if (!((__ballot(valid) >> j) & 1ull)) continue;  // (uniform: j was a copy of an earlier key)
-        const u64 kj = lane_u64(key, j);
-        const bool other = valid & (lane != j);
-        r += (other & (kj < key)) ? 1u : 0u;
-        valid = valid & !(other & (kj == key) & (j < lane));
+    {
+        bool dupc = false;
+        for (u64 it = __ballot(valid); it; it &= it - 1) {
+            const int j = __ffsll((long long)it) - 1;
+            const u64 kj = lane_u64(key, j);
+            r += (kj < key) ? 1u : 0u;
+            dupc = dupc | ((kj == key) & (j < lane));
+        }
+        if (__ballot(valid & dupc)) {  // (the copies go; ranks once more over what is left)
+            valid = valid & !dupc;
+            r = 0;
+            for (u64 it = __ballot(valid); it; it &= it - 1) {
+                const int j = __ffsll((long long)it) - 1;
+                r += (lane_u64(key, j) < key) ? 1u : 0u;
+            }
+        }
     }
     const u64 vm = __ballot(valid);
     if (vm == 0) return;
@@ -327,50 +357,70 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
         *front = nf < L ? nf : L;
         *ub += below;
     }
-    // Shift, top segment first: the entries from the rank-t survivor's lower bound up to the next survivor's (the pool's end for the
-    // last one) move up by t + 1.  64-entry chunks, top chunk first, up to four chunks read before the first is written back: the LDS
-    // executes a wave's instructions in order, a lower chunk's reads never overlap an upper chunk's (higher) write range, and a lower
-    // chunk's writes come after the upper chunk's reads in program order -- so no wait is needed in between.
-    uint32_t hi = P;
-    for (uint32_t t = s; t-- > 0;) {
+    lap(1);
+    // ---- (3) shift.  The entry at index i moves up by the number of survivors whose lower bound is <= i; the rank-t survivor goes to its
+    // lower bound + t.  Chunks of 64 entries on absolute boundaries, top chunk first.  What a chunk costs is its INSTRUCTIONS (a first form
+    // of this walk ran one general body per chunk -- forty instructions each -- and took as long as the segment-wise shift it replaced:
+    // 2 400 cycles per hop at L_pq = 1 000), so: a chunk that no survivor lands in and that stays inside the pool is a read and a write
+    // with one uniform amount, four such chunks are read before the first is written back; only the chunks with a landing point, and the
+    // top chunk(s) when entries fall off the pool's end, run the general body (a lane subtracts one per landing point above its entry).
+    auto landing = [&](uint32_t t) -> uint32_t {  // lower bound of the rank-t survivor (nondecreasing in t)
         const int l = __ffsll((long long)__ballot(valid & (r == t))) - 1;
-        const uint32_t seg_lo = lane_u32(lo, l), sh = t + 1u;
-        for (uint32_t top = hi; top > seg_lo;) {
-            const uint32_t left = top - seg_lo;
-            if (left >= 256u && top + sh <= L) {  // four whole chunks that stay inside the pool: no lane has anything to decide
-                u64 e[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) e[u] = pool[top - 64u * (uint32_t)(u + 1) + (uint32_t)lane];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pool[top - 64u * (uint32_t)(u + 1) + (uint32_t)lane + sh] = e[u];
-                top -= 256u;
-            } else if (left >= 64u && top + sh <= L) {
-                const u64 e = pool[top - 64u + (uint32_t)lane];
-                pool[top - 64u + (uint32_t)lane + sh] = e;
-                top -= 64u;
-            } else {  // the chunk at the pool's end when it is full (entries pushed past L_pq are dropped) and the segment's last, partial one
-                const uint32_t lo_c = left > 64u ? top - 64u : seg_lo;
-                const uint32_t kidx = lo_c + (uint32_t)lane;
-                const bool a = kidx < top;
-                const u64 e = pool[a ? kidx : lo_c];
-                if (a & (kidx + sh < L)) pool[kidx + sh] = e;
-                if (tp.vis) {
-                    if (a & !(kidx + sh < L)) tag_protect(tp, (uint32_t)e >> 1, false);  // fell off the pool's end
+        return lane_u32(lo, l);
+    };
+    const uint32_t pmin = landing(0);
+    if (P > pmin) {
+        uint32_t t_rem = s;                            // survivors landing below the end of the chunk in hand (the others are taken off)
+        uint32_t lp = s > 1u ? landing(s - 1u) : pmin;  // lower bound of survivor t_rem - 1
+        int c = (int)((P - 1u) >> 6);
+        while (t_rem > 0u) {
+            const uint32_t base = (uint32_t)c << 6;
+            if (lp >= base || base + 64u + t_rem > L || base + 64u > P) {
+                // general body: landing points inside, or entries that fall off the pool's end, or the pool's partial top chunk
+                const uint32_t i = base + (uint32_t)lane;
+                const u64 e = pool[i < P ? i : Pm1];
+                uint32_t shl = t_rem;
+                while (t_rem > 0u && lp >= base) {  // entries below a landing point do not move for it
+                    shl -= (i < lp) ? 1u : 0u;
+                    --t_rem;
+                    if (t_rem > 0u) lp = landing(t_rem - 1u);
                 }
-                top = lo_c;
+                const bool a = (i < P) & (shl > 0u);
+                const uint32_t dest = i + shl;
+                if (a & (dest < L)) pool[dest] = e;
+                if (tp.vis) {
+                    if (a & !(dest < L)) tag_protect(tp, (uint32_t)e >> 1, false);  // fell off the pool's end
+                }
+                --c;
+            } else {
+                // whole chunks down to (not including) the chunk of the next landing point, all by t_rem
+                uint32_t n = (uint32_t)c - (lp >> 6);
+                const uint32_t amount = t_rem;
+                u64 *src = pool + base + (uint32_t)lane;
+                for (; n >= 4u; n -= 4u, src -= 256) {
+                    u64 e4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e4[u] = src[-64 * u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) src[-64 * u + (int)amount] = e4[u];
+                }
+                for (; n > 0u; --n, src -= 64) {
+                    const u64 e1 = src[0];
+                    src[amount] = e1;
+                }
+                c = (int)(lp >> 6);
             }
         }
-        hi = seg_lo;
     }
-    const uint32_t pmin = hi;  // the rank-0 survivor's lower bound
     wave_sync();
+    lap(2);
     if (valid && lo + r < L) {
         pool[lo + r] = key;
         if (tp.vis) tag_protect(tp, (uint32_t)key >> 1, true);
     }
     psize = (P + s < L) ? P + s : L;
-    const uint32_t c = uni(cur);
-    cur = c < pmin ? c : pmin;  // neighbor.h:180-182
+    const uint32_t c0 = uni(cur);
+    cur = c0 < pmin ? c0 : pmin;  // neighbor.h:180-182
     wave_sync();
 }
 

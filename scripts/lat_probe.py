@@ -14,16 +14,20 @@ ap.add_argument("--graph-cache", default="/tmp/roar_graph.index")
 ap.add_argument("--L", type=int, nargs="+", default=[55])
 ap.add_argument("--nqs", type=int, nargs="+", default=[1, 256, 1250, 2500, 10000])
 ap.add_argument("--vis", type=int, default=1)
+ap.add_argument("--tags", type=int, default=0, help="option vis_entries (0: the plan's own)")
+ap.add_argument("--kernels", type=int, nargs="+", default=[1, 3, 2], help="option search_kernel values (1 one wave per query, 3 two, 2 four)")
 args = ap.parse_args()
 n, d, k = args.n, 200, 10
 from _graph import t2i_index
 idx, base, queries = t2i_index(n, 10000, args.builder, 0, args.graph_cache)
 idx.set_option("visited_mode", args.vis)
+if args.tags:
+    idx.set_option("calibrate", 0), idx.set_option("screen", 2), idx.set_option("vis_entries", args.tags)
 names = ["select", "adj", "filter", "score", "merge"]
 for L in args.L:
     for nq in args.nqs:
         q = queries[:nq].contiguous()
-        for kern in (1, 3, 2):
+        for kern in args.kernels:
             if kern != 1 and nq > 2500: continue
             idx.set_option("search_kernel", kern)
             idx.set_option("profile_phases", 0)
@@ -43,4 +47,5 @@ for L in args.L:
                   f"cycles/hop {pr[:, 0].sum() / H:7.0f}: {ph} | per pass: issue {pr[:, 8].sum() / max(pr[:, 11].sum(), 1):6.0f} "
                   f"wait+fma {pr[:, 9].sum() / max(pr[:, 11].sum(), 1):6.0f} tail {pr[:, 10].sum() / max(pr[:, 11].sum(), 1):6.0f}, "
                   f"passes/hop {pr[:, 11].sum() / H:.2f} rows/hop {out['cmps'].double().sum().item() / H:.1f} survivors/hop {pr[:, 12].sum() / H:.1f} "
-                  f"spec hit {pr[:, 6].sum() / H:.2f} | query cycles mean {pr[:, 0].mean():.0f} max {pr[:, 0].max():.0f}", flush=True)
+                  f"spec hit {pr[:, 6].sum() / H:.2f} | query cycles mean {pr[:, 0].mean():.0f} max {pr[:, 0].max():.0f} | "
+                  f"inside the merge (LDS pool): lower bounds {pr[:, 13].sum() / H:.0f} ranks {pr[:, 14].sum() / H:.0f} shift {pr[:, 15].sum() / H:.0f}", flush=True)

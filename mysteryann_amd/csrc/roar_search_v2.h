@@ -1178,20 +1178,39 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         if (cur >= psize) {
                             done = true;
                         } else {
-                            const u64 e = pool[cur];
+                            // ONE read serves the entry itself (lane 0), the search for the next unexpanded entry when it starts right behind
+                            // it (lanes 1-63: the common case) and that entry's id -- the target of the speculative adjacency fetch, which
+                            // rounds 3-5 read again from pool[cur] after the filter: three or four dependent LDS round trips per hop less
+                            const uint32_t w0 = cur + (uint32_t)lane;
+                            const u64 ew = pool[w0 < psize ? w0 : cur];
+                            const u64 e = lane_u64(ew, 0);
                             v = (uint32_t)e >> 1;
                             if (lane == 0) pool[cur] = e | 1ull;
                             wave_sync();
                             if (cur < front) ub = ub ? ub - 1u : 0u;
                             else front = cur + 1u, ub = 0;
                             uint32_t found = psize;
-                            for (uint32_t c = (ub == 0 && front > cur + 1u) ? front : cur + 1u; c < psize; c += 64) {
-                                const uint32_t kidx = c + (uint32_t)lane;
-                                const bool unf = kidx < psize && !(pool[kidx] & 1ull);
-                                const u64 b = __ballot(unf);
+                            uint32_t c = (ub == 0 && front > cur + 1u) ? front : cur + 1u;
+                            if (c == cur + 1u) {
+                                const u64 b = __ballot(lane >= 1 && w0 < psize && !(ew & 1ull));
                                 if (b) {
-                                    found = c + (uint32_t)__ffsll((long long)b) - 1u;
-                                    break;
+                                    const int l = __ffsll((long long)b) - 1;
+                                    found = cur + (uint32_t)l;
+                                    nextv = lane_u32((uint32_t)ew, l) >> 1;
+                                }
+                                c = cur + 64u;
+                            }
+                            if (found == psize) {
+                                for (; c < psize; c += 64) {
+                                    const uint32_t kidx = c + (uint32_t)lane;
+                                    const u64 ek = pool[kidx < psize ? kidx : cur];
+                                    const u64 b = __ballot(kidx < psize && !(ek & 1ull));
+                                    if (b) {
+                                        const int l = __ffsll((long long)b) - 1;
+                                        found = c + (uint32_t)l;
+                                        nextv = lane_u32((uint32_t)ek, l) >> 1;
+                                        break;
+                                    }
                                 }
                             }
                             cur = found;
@@ -1237,6 +1256,8 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                 } else if constexpr (RP) {  // a row longer than 191 entries continues (its next words are already here)
                     const u64 um = __ballot((uint32_t)lane < psize && !(pk & 1ull));
                     if (um) nextv = (uint32_t)lane_u64(pk, __ffsll((long long)um) - 1) >> 1;
+                } else {
+                    if (cur < psize) nextv = (uint32_t)pool[cur] >> 1;
                 }
                 if (!done) {
                     // visited filter over the whole round trip (index_bipartite.cpp:2378-2385), survivors packed in cid
@@ -1316,8 +1337,7 @@ __device__ __forceinline__ void search_v2(const RoarSearchParams &p) {
                         const uint32_t *nrow = arow + wpos;
                         bool whole = true;  // the rest of a long row: every chunk; the next row, plain form: its first chunk
                         if (wpos > deg) {
-                            if constexpr (RP) pf = (nextv != NONE) ? nextv : vcur;  // (nothing left: any valid row)
-                            else pf = (cur < psize) ? (uint32_t)pool[cur] >> 1 : vcur;
+                            pf = (nextv != NONE) ? nextv : vcur;  // (nothing left: any valid row)
                             nrow = ADJ + (u64)pf * AS;
                             whole = HUB;
                         }

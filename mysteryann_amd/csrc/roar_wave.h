@@ -287,21 +287,21 @@ __device__ __forceinline__ void merge_candidates(u64 *pool, const u64 *ck, uint3
     // through per-lane arithmetic were vector values and every `if` below a save / mask / restore of EXEC.
     const uint32_t m = uni(m_), L = uni(L_), P = uni(psize), Pm1 = P ? P - 1u : 0u;
     bool valid = (uint32_t)lane < m;
+    // (the three reads nothing here depends on go out together: the candidates' keys, the pool's last entry -- read whether the pool is
+    // full or not, used if it is -- and the splitters: one LDS round trip in front of the lower bounds instead of three)
+    // segment l = entries [l step, (l + 1) step) cut at P; its splitter = its last entry (segments past the end repeat the pool's last)
+    const uint32_t step = (P + 63u) >> 6;
+    const uint32_t e_l = P ? ((uint32_t)(lane + 1) * step < P ? (uint32_t)(lane + 1) * step : P) - 1u : 0u;
     u64 key = ck[(uint32_t)lane < m ? lane : 0];
+    const u64 last = pool[L - 1] & ~FLAG;
+    const u64 spl = pool[e_l] & ~FLAG;
     key = valid ? key : ~0ull;
-    if (P == L) {  // neighbor.h:151-153
-        const u64 last = pool[L - 1] & ~FLAG;
-        valid = valid & (key < last);
-    }
+    if (P == L) valid = valid & (key < last);  // neighbor.h:151-153
     const u64 vm0 = __ballot(valid);
     if (vm0 == 0) return;
     // ---- (1) lower bound of key among the (flag-masked) pool keys, and "already in the pool"
     uint32_t lo = 0, len = P, span = P;  // (span: the longest range any lane still has to search)
     if (P > 128u) {
-        // segment l = entries [l step, (l + 1) step) cut at P; its splitter = its last entry (segments past the end repeat the pool's last)
-        const uint32_t step = (P + 63u) >> 6;
-        const uint32_t e_l = ((uint32_t)(lane + 1) * step < P ? (uint32_t)(lane + 1) * step : P) - 1u;
-        const u64 spl = pool[e_l] & ~FLAG;
         uint32_t seg = 0;
         for (u64 it = vm0; it; it &= it - 1) {
             const int j = __ffsll((long long)it) - 1;

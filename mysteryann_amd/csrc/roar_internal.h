@@ -153,6 +153,7 @@ struct roar_index {
         int protect;
         float best_ms, default_ms;
         uint32_t sample, L, runs;
+        uint32_t wpc = 0;  // workgroups per CU the winning plan kept resident when it was measured (0: not recorded)
     };
     std::vector<Calibration> plan_cache;
     int calibrate = 1;
@@ -261,6 +262,7 @@ struct roar_index {
     int64_t last_combined = 0;
     // last launch
     int64_t last_grid = 0, last_lds = 0, last_vis_entries = 0;
+    int last_wpc = 0;  // workgroups per CU of the last plan (before the grid is cut to the batch or a cap)
     std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel form, LDS bytes) -> resident workgroups per CU
     std::atomic<int> streams_open{0};  // roar_search_stream_open .. _close: base rows and graph must stay as they are meanwhile
 };

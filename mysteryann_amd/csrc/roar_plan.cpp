@@ -283,6 +283,7 @@ int plan_search(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan
     // (Rounds 2-3 launched six one-wave workgroups per CU with the on-chip table and no screen although the LDS allows eight: 1 % on the
     // 10 M-point benchmark -- 3.593 against 3.635 ms -- and a handicap wherever a launch is bound by latency, e.g. any set that fits the
     // caches; the cap went with the other constants measured on one graph.  Option "waves_per_cu" still sets it.)
+    idx->last_wpc = wpc;
     uint64_t grid = (uint64_t)wpc * (uint64_t)idx->n_cus;
     if (grid > nq) grid = nq;
     if (idx->max_grid > 0 && grid > (uint64_t)idx->max_grid) grid = idx->max_grid;
@@ -384,8 +385,13 @@ bool calibratable(const roar_index *idx) {
 }
 
 uint64_t plan_key(const roar_index *idx, uint64_t nq, uint32_t L) {
-    uint32_t lband = 0;  // half-octave bands of L_pq: [2^(b/2), 2^((b+1)/2))
+    uint32_t lband = 0;  // half-octave bands of L_pq: [2^(b/2), 2^((b+1)/2)) ...
     while (lband < 40 && std::pow(2.0, 0.5 * (lband + 1)) <= (double)L) lband++;
+    // ... up to L_pq = 512; beyond, one band per 1 280-byte LDS block of the pool (160 entries): a long pool's table is chosen against
+    // what the pool leaves of the CU's LDS, and a pick made at L_pq = 1 500 (3 072 tags, eight workgroups per CU) ran the launches at
+    // 1 600-1 900 of the same half-octave at seven and six per CU -- 3-12 % behind the smaller table round 5 had picked there
+    // (profiles/r06_sweep_t2i10m.csv, first pass)
+    if (L >= 512u) lband = 32u + std::min<uint32_t>(200u, round_up(8u * (L + 1u), 16u) / 1280u);
     // batch bands by queries per CU: 1, 2, 4, 6, 8, 10, 12, more -- fine around the residency limit (6-12 single-wave workgroups per CU
     // by LDS and registers), where a table's size decides whether the whole batch is resident (1 250 and 2 500 queries want different
     // tables on the benchmark graph: 0.415 / 0.431 ms with 8 192 / 4 096 tags against 0.719 / 0.559 ms)
@@ -494,6 +500,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         int mode, screen;
         int protect = -1;  // (-1: whatever the default rule gave; the last stage fixes it)
         uint32_t grid = 0;  // workgroups of the timed launch (the sample is at least one residency: how many the plan keeps resident)
+        uint32_t wpc = 0;   // ... per CU, as the LDS and the registers allow (before the grid is cut to the sample)
     };
     std::vector<Cand> tried;
     tried.reserve(16);
@@ -503,6 +510,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         Cand c{pk, -1.f, 0, 0, 0, protect};
         c.ms = time_pick(pk, &c.entries, &c.mode, &c.screen);
         c.grid = (uint32_t)idx->last_grid;
+        c.wpc = (uint32_t)idx->last_wpc;
         if (c.ms < 0.f) return nullptr;
         for (const Cand &o : tried)  // (a table below the minimum for this many points is planned as the minimum: the same launch)
             if (o.entries == c.entries && o.mode == c.mode && o.screen == c.screen && o.protect == c.protect) return nullptr;
@@ -523,7 +531,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         if (default_ms >= 0.f) {
             PlanPick pk;
             pk.screen = su, pk.mode = mu, pk.entries = mu == ROAR_VISITED_LDS ? eu : 0;
-            tried.push_back(Cand{pk, default_ms, eu, mu, su, -1, (uint32_t)idx->last_grid});
+            tried.push_back(Cand{pk, default_ms, eu, mu, su, -1, (uint32_t)idx->last_grid, (uint32_t)idx->last_wpc});
             if (log)
                 fprintf(stderr, "[roar calibration] L_pq=%u sample=%u: default plan (screen %s, %s, %u tags): %.3f ms\n", L, S,
                         su ? "on" : "off", mu == ROAR_VISITED_EXACT ? "HBM tags" : "on-chip table", eu, default_ms);
@@ -554,27 +562,36 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
         // stage 2: further in the direction that won, while it keeps winning (a smaller table buys resident workgroups -- a long pool
         // leaves room for nine to twelve per CU and every 1 280 bytes count -- a bigger one forgets less), then the 3 x 2^k size next to
         // the winner
+        // (the descent follows the best ON-CHIP table, whether or not the HBM tags lead at this point -- they are the default plan from
+        // L_pq = 1 536 on, and a 4 096-tag table a little behind them said nothing about the 2 048-tag one: T2I-10M, L_pq = 1 600, HBM tags
+        // 58-64 ms run to run, 4 096 tags 59.9, 2 560 tags 49.1 -- the sweep's run kept the HBM tags, the probe's the table)
+        auto best_table = [&]() -> const Cand * {
+            const Cand *b = nullptr;
+            for (const Cand &c : tried)
+                if (c.mode == ROAR_VISITED_LDS && (!b || c.ms < b->ms)) b = &c;
+            return b;
+        };
         if (!hard_error && entries_free) {
-            const Cand *b = best_of();
-            if (b && b->mode == ROAR_VISITED_LDS) {
+            const Cand *b = best_table();
+            if (b) {
                 const int sc = screen_free ? b->screen : -1;
                 if (b->entries <= 4096) {
                     for (uint32_t e = 2048; e >= 1024 && !hard_error; e >>= 1) {
                         const Cand *c = try_pick(sc, ROAR_VISITED_LDS, e);
-                        b = best_of();
-                        if (!c || !b || b->entries != c->entries || b->mode != ROAR_VISITED_LDS) break;  // (did not win: stop here)
+                        b = best_table();
+                        if (!c || !b || b->entries != c->entries) break;  // (did not win: stop here)
                     }
                 } else if (b->entries >= 8192) {
                     try_pick(sc, ROAR_VISITED_LDS, 16384);
                 }
-                b = best_of();
-                if (!hard_error && b && b->mode == ROAR_VISITED_LDS && L >= 256 && b->entries >= 1024 && b->entries <= 4096) {
+                b = best_table();
+                if (!hard_error && b && L >= 256 && b->entries >= 1024 && b->entries <= 4096) {
                     const uint32_t e0 = b->entries;
                     try_pick(sc, ROAR_VISITED_LDS, e0 + e0 / 2);
                     if (!hard_error && (e0 & (e0 - 1)) == 0) try_pick(sc, ROAR_VISITED_LDS, e0 - e0 / 4);
                     // the 5 * 2^k sizes on both sides of the winner (1 280 between 1 024 and 1 536 ...): at a long pool 256 tags are a workgroup per CU
-                    b = best_of();
-                    if (!hard_error && b && b->mode == ROAR_VISITED_LDS) {
+                    b = best_table();
+                    if (!hard_error && b) {
                         const uint32_t eb = b->entries;
                         uint32_t lo5 = 640;
                         while (lo5 * 2 < eb) lo5 *= 2;  // the largest 5 * 2^k below the winner; twice that is the smallest above it
@@ -668,7 +685,8 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     out->protect = idx->tag_protect < 0 ? best->protect : -1;
     *calibrated = true;
     try {
-        roar_index::Calibration c{key, out->screen, out->mode, out->entries, out->protect, best->ms, default_ms, S, L, runs};
+        roar_index::Calibration c{key, out->screen, out->mode, out->entries, out->protect, best->ms, default_ms, S, L, runs,
+                                  (best->mode == ROAR_VISITED_LDS && out->entries) ? best->wpc : 0u};
         idx->plan_cache.push_back(c);
     } catch (...) {
     }
@@ -684,6 +702,36 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
 // has not been seen yet), defaults otherwise.  *need_queries (may be null): set when a calibration is due but qdev is null.
 uint64_t stream_calibration_min_queries(const roar_index *idx) { return (uint64_t)std::max(idx->n_cus, 1) * 12u; }
 
+// A cached pick, applied at THIS L_pq: the table it names was chosen against the LDS the pool left at the L_pq it was measured at; a
+// longer pool of the same band may leave room for one workgroup per CU less with it (a band spans a 1 280-byte block of pool: at most
+// one residency step).  A long pool lives on resident workgroups, so the table steps down -- 3/4, 5/8, 1/2 ... of itself, to 1 024
+// tags or the smallest the point count allows -- until the plan keeps what the measurement had (T2I-10M: the pick of L_pq = 1 600,
+// 2 560 tags at eight per CU, served 1 700 at seven: 3.7 % behind round 5; profiles/r06_sweep_t2i10m.csv).
+int plan_with_cached_pick(roar_index *idx, uint64_t nq, uint32_t k, uint32_t L, LaunchPlan *plan, PlanPick pick, uint32_t want_wpc) {
+    int e = plan_search(idx, nq, k, L, plan, false, &pick);
+    if (e || want_wpc == 0 || pick.entries == 0) return e;
+    static const uint32_t steps[] = {16384, 12288, 10240, 8192, 6144, 5120, 4096, 3072, 2560, 2048, 1536, 1280, 1024};
+    while ((uint32_t)idx->last_wpc < want_wpc && idx->last_mode == ROAR_VISITED_LDS) {
+        const uint32_t have = (uint32_t)idx->last_vis_entries;
+        uint32_t next = 0;
+        for (uint32_t st : steps)
+            if (st < have) {
+                next = st;
+                break;
+            }
+        if (next == 0) break;
+        pick.entries = next;
+        LaunchPlan smaller;
+        if ((e = plan_search(idx, nq, k, L, &smaller, false, &pick))) return e;
+        if ((uint32_t)idx->last_vis_entries >= have) {  // (the point count allows nothing smaller: the plan before it stands)
+            pick.entries = have;
+            return plan_search(idx, nq, k, L, plan, false, &pick);
+        }
+        *plan = smaller;
+    }
+    return ROAR_OK;
+}
+
 int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
                  bool *need_queries) {
     if (need_queries) *need_queries = false;
@@ -696,6 +744,7 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
     if (const roar_index::Calibration *c = find_calibration(idx, key)) {
         pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
         idx->last_calibrated = 1;
+        return plan_with_cached_pick(idx, nq, k, L, plan, pick, L > c->L ? c->wpc : 0u);
     } else if (idx->max_grid > 0 && nq < stream_calibration_min_queries(idx)) {
         // a launch under a grid cap takes the calibration of the largest batches (plan_key) -- which a sample of less than one
         // residency of the chip cannot make: defaults for this call, nothing cached
@@ -716,6 +765,7 @@ int resolve_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstri
 int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qstride, uint32_t k, uint32_t L, hipStream_t st, LaunchPlan *plan,
                         bool *provisional) {
     PlanPick pick;
+    uint32_t want_wpc = 0;
     idx->last_calibrated = 0;
     if (provisional) *provisional = false;
     const bool sane = idx->base && idx->adj && idx->gn == idx->n && L != 0 && k != 0 && k <= L;  // (else: plan_search words the error)
@@ -729,6 +779,7 @@ int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_
         if (const roar_index::Calibration *c = find_calibration(idx, key)) {
             pick.screen = c->screen, pick.mode = c->mode, pick.entries = c->entries, pick.protect = c->protect;
             idx->last_calibrated = 1;
+            if (L > c->L) want_wpc = c->wpc;
         } else if (nq < stream_calibration_min_queries(idx)) {
             // as resolve_plan does for a launch under a grid cap: a sample of less than one residency of the chip cannot make the calibration
             // of the largest batches (every table ties, noise picks -- and the pick would be cached for every later stream and capped launch
@@ -744,6 +795,6 @@ int resolve_stream_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_
     }
     if (pick.mode == ROAR_VISITED_EXACT) pick.mode = -1, pick.entries = 0;  // (HBM tags won the calibration: the stream runs the table anyway)
     pick.stream = 1;
-    return plan_search(idx, 1ull << 30, k, L, plan, false, &pick);
+    return plan_with_cached_pick(idx, 1ull << 30, k, L, plan, pick, want_wpc);
 }
 }  // namespace roar_impl

@@ -402,7 +402,10 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    down to 1 024 tags and the 3 x 2^k sizes between them, HBM tags for long pools) on the first (at most
  *                    12 288) queries of that call, results into scratch buffers, and keeps the fastest for the launches that follow
  *                    (that call synchronises its stream; results never depend on the plan; ROAR_LOG_CALIBRATION=1 in the environment
- *                    prints every decision); 0: fixed defaults (screen on for rows of 768 bytes and more, the on-chip table with
+ *                    prints every decision).  L_pq bands: half-octaves up to 512, 160 entries (one 1 280-byte LDS block of pool) beyond;
+ *                    launches that share the chip (grid cap, stream) have entries of their own, ranked by resident workgroups among
+ *                    candidates within 2 % of the fastest; a cached table steps down when a longer pool of its band would otherwise
+ *                    keep fewer workgroups resident than it was measured with; 0: fixed defaults (screen on for rows of 768 bytes and more, the on-chip table with
  *                    4 096 / 8 192 tags up to L_pq = 1 536, HBM tags beyond); 2: forget what was measured so far
  *   "tag_protect"    forgetful on-chip tag table under a candidate pool in LDS (L_pq > 64, one wave per query, device or pinned queries):
  *                    1 = a tag whose node is in the pool is never the victim of an insertion (bit 15 of the tag, kept by the queue's

@@ -423,7 +423,7 @@ int roar_sharded_info(roar_sharded *sh, const char *key, int64_t *value);
  *                    tests/test_search_roargraph.cpp:203-209); 0: one launch per call
  * roar_get_info keys: "n", "dim", "dim_padded", "ep", "max_degree", "nedges", "adj_stride",
  *   "bipartite_nodes", "bipartite_edges", "last_combined" (queries carried by the most recent combined launch),
- *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_lds_bytes",
+ *   "row_stride", "graph_hash" (64-bit hash of the device rows and the entry point), "last_grid", "last_workgroups_per_cu" (what the last plan keeps resident per CU, before the grid is cut to the batch or a cap), "last_lds_bytes",
  *   "last_vis_entries", "last_waves_per_query", "last_register_pool", "last_hub_bitmap", "last_screen", "screen_row_bytes" (bytes per
  *   row of the 8-bit screening copy at this dimension), "last_visited_forgetful", "last_tag_protect", "last_plan_calibrated" (1 if the most recent search ran a measured plan),
  *   "calibrations" (launch kinds measured so far), "last_knn_bf16" (1 if the most recent exact kNN call ran the bf16-screened form), "last_knn_rerank_rows" (rows it scored on f32), "last_kernel_ns"

@@ -331,6 +331,7 @@ int roar_get_info(roar_index *idx, const char *key, int64_t *value) {
         *value = (int64_t)idx->graph_hash;
     }
     else if (k == "last_grid") *value = idx->last_grid;
+    else if (k == "last_workgroups_per_cu") *value = idx->last_wpc;
     else if (k == "last_lds_bytes") *value = idx->last_lds;
     else if (k == "last_vis_entries") *value = idx->last_vis_entries;
     else if (k == "last_kernel_ns") {

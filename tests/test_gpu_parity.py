@@ -964,6 +964,40 @@ def test_auto_plan_on_a_graph_nobody_tuned_for(built_lib):
     idx.close()
 
 
+def test_a_cached_plan_keeps_its_residency_at_a_longer_pool_of_its_band(built_lib):
+    """Round 6: beyond L_pq = 512 a calibration serves a band of 160 pool lengths (one 1 280-byte LDS block of pool); applied at a
+    longer pool of its band the measured table must not cost a resident workgroup per CU -- it steps down (3/4, 5/8, 1/2 ... of itself)
+    until the plan keeps what the measurement had, or the table is at its smallest.  Results equal the oracle's at both lengths."""
+    import torch
+
+    import oracle
+    from mysteryann_amd import index as mi
+
+    n, d, nq = 60_000, 200, 3200
+    base, q, off, nbrs = _random_case(n, d, nq, 1, seed=71, maxdeg=40)
+    ep = int(np.argmax(np.diff(off.astype(np.int64)) > 10))  # (an entry point that has neighbours: the random degrees start at 0)
+    idx = mi.IndexBipartite(d, n, 1, None)
+    idx.SetBaseData(base)
+    idx.SetProjectionGraph(ep, off, nbrs)
+    qd = torch.from_numpy(q).cuda()
+    seen = {}
+    for L in (1601, 1755):  # the first and (nearly) the last pool length of one band: 8 (L + 1) bytes = 10 blocks of 1 280
+        out = idx.SearchRoarGraphBatchDevice(qd, K, L)
+        torch.cuda.synchronize()
+        seen[L] = dict(cal=idx.info("calibrations"), wpc=idx.info("last_workgroups_per_cu"), tags=idx.info("last_vis_entries"),
+                       mode=idx.info("last_visited_mode"), lds=idx.info("last_lds_bytes"))
+        o = oracle.search_batch(base, off, nbrs, ep, q[:64], K, L, 1, threads=8)
+        assert int(o["hops"].min()) > L // 2  # (a real search: the pool fills)
+        for key in ("ids", "dists", "hops"):
+            assert np.array_equal(out[key][:64].cpu().numpy().view(o[key].dtype), o[key]), (L, key)
+    a, b = seen[1601], seen[1755]
+    assert a["cal"] == 1 and b["cal"] == 1, seen  # one band, one calibration
+    if a["mode"] == 1 and a["tags"] > 1024:  # (an on-chip table was picked: the rule applies)
+        assert b["wpc"] >= a["wpc"] or b["tags"] <= 1024, seen
+        assert b["tags"] <= a["tags"], seen
+    idx.close()
+
+
 def test_auto_screen_decision_follows_the_measured_times(built_lib):
     """Where the 8-bit screen pays is a property of the data -- how many of a hop's neighbours its bound can drop:
       * isotropic rows (t2i-hard, offset 0): scores spread over many slacks of the bound, most rows are dropped;

@@ -8,7 +8,7 @@ cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx9
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = b.split()[0]
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     m = re.search(r"(\w+)<(.*)>\(", dem)
     short = f"{m.group(1)}<{m.group(2)}>" if m else dem[:80]
     g = lambda k: int(re.search(k + r": (\d+)", b).group(1))

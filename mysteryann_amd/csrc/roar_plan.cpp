@@ -575,7 +575,9 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
             const Cand *b = best_table();
             if (b) {
                 const int sc = screen_free ? b->screen : -1;
-                if (b->entries <= 4096) {
+                // (a smaller table buys resident workgroups and nothing else: where the whole sample was resident with the best table so
+                // far -- a launch of a few dozen queries -- there is nothing to buy, only noise to pick from and rows to forget)
+                if (b->entries <= 4096 && b->grid < S) {
                     for (uint32_t e = 2048; e >= 1024 && !hard_error; e >>= 1) {
                         const Cand *c = try_pick(sc, ROAR_VISITED_LDS, e);
                         b = best_table();
@@ -585,7 +587,7 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
                     try_pick(sc, ROAR_VISITED_LDS, 16384);
                 }
                 b = best_table();
-                if (!hard_error && b && L >= 256 && b->entries >= 1024 && b->entries <= 4096) {
+                if (!hard_error && b && L >= 256 && b->entries >= 1024 && b->entries <= 4096 && b->grid < S) {
                     const uint32_t e0 = b->entries;
                     try_pick(sc, ROAR_VISITED_LDS, e0 + e0 / 2);
                     if (!hard_error && (e0 & (e0 - 1)) == 0) try_pick(sc, ROAR_VISITED_LDS, e0 - e0 / 4);
@@ -669,7 +671,12 @@ int calibrate_plan(roar_index *idx, const float *qdev, uint64_t nq, uint32_t qst
     // (eight workgroups per CU) is 3 % slower than the 4 096-tag one (twelve) for 10 000-query batches and 4.7 % slower for 1 250-query ones
     // (profiles/r06_table_regime_probe.txt) -- the driver's round-5 run picked it on a 0.6 % "win" and lost 3 % of `value`.
     {
-        const float lim = best->ms * (shared ? 1.02f : 1.005f);
+        // (a sample that was resident as a whole with every candidate -- a small launch, timed in a fraction of a millisecond -- cannot
+        // tell the tables apart by residency, and its timings scatter by percents: the tie is 5 % wide there, and the bigger table --
+        // it forgets less -- takes it)
+        bool all_resident = true;
+        for (const Cand &c : tried) all_resident = all_resident && c.grid >= S;
+        const float lim = best->ms * (all_resident ? 1.05f : shared ? 1.02f : 1.005f);
         auto fidelity = [&](const Cand &c) -> uint64_t {
             return ((uint64_t)(c.mode == ROAR_VISITED_EXACT ? 1 : 0) << 60) | ((uint64_t)(c.grid & 0xFFFFFu) << 36) | ((uint64_t)c.entries << 8) |
                    (uint64_t)(&c == &tried.front() ? 1 : 0);

@@ -444,7 +444,11 @@ __device__ __forceinline__ void screen8i_pass(const unsigned char *__restrict__ 
         const uint32_t bn = x[r][NJ].w;
         const float sc = __uint_as_float(x[r][NJ].z), bnd = __uint_as_float(bn << 16), nrm = __uint_as_float(bn & 0xFFFF0000u);
         // the exact distance is >= lower - qd; qd, the same for every row of the query, sits in the threshold (screen_threshold)
+#ifdef ROAR_SCREEN_SLACK_MUL  // measurement builds only: the row side of the bound as codes of fewer bits would have it (profiles/r06_coarser_screen_probe.txt)
+        const float lower = -((sc * qb) * (float)I) - (qc * nrm + (float)(ROAR_SCREEN_SLACK_MUL) * qa * bnd) - 1.0e-30f;
+#else
         const float lower = -((sc * qb) * (float)I) - (qc * nrm + qa * bnd) - 1.0e-30f;
+#endif
         const uint32_t c = p0 + 16 * r + g;
         float th = thr_d;
         if constexpr (CHECK) th = chk[c < m ? c : m - 1];
